@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py -- attack iterations/sec of the MI355X hot path, with roofline and CPU-baseline legs.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W        (N > 1: launched through torch.distributed.run)
+
+  * workload = BASELINE.json configs[1]: ResNet-18 (1000 classes, random init), ImageNet-shaped 1x3x224x224 candidate,
+    attack=invertinggradients (cosine-similarity gradient matching + TV 0.2, hard-sign Adam lr 0.1, box projection,
+    step-lr schedule of the full 24 000-iteration run).  Synthetic data, inputs resident in HBM before timing starts.
+  * a "step" = one attack iteration (`optimizer.step(closure)` of optimization_based_attack.py:110-121): victim
+    forward + backward + double backward on PyTorch-ROCm, kernels A/B/C of libbreach_hip.so for everything else.
+  * N GPUs = N independent restarts (trials), one per rank (weak scaling); value = N*K / max-over-ranks wall time.
+    After the timed region the ranks agree on the best trial with ONE all-reduce(MIN) + one broadcast (RCCL).
+  * roofline: the fused gradient-matching reduction (kernel A forward, gm_fwd_kernel): algorithmic bytes 2*N*4 per launch
+    over the average launch duration measured with HIP events on the launch stream inside the timed region.
+  * cpu_baseline: oracle/restate.py (CPU restatement of the reference, pinned to it by tests/test_oracle_pinning.py) on
+    the host cores, same workload, a bounded number of iterations, rank 0 at N=1 only.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--cpu-baseline-iters", type=int, default=6, help="timed CPU iterations of the oracle (0 disables)")
+    p.add_argument("--model", default="resnet18")
+    p.add_argument("--no-kernel-timing", action="store_true")
+    return p.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import breaching_amd
+    from breaching_amd import trials
+    from breaching_amd.attacker import FusedTrial
+    from breaching_amd.cases import build_case, initial_candidate
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- workload --------------------------------------------------------------------------------------------------
+    torch.manual_seed(0)
+    case = build_case(args.model, "ImageNet", 1, device=device, gradient_device=device)
+    cfg = breaching_amd.get_attack_config("invertinggradients", [f"restarts.num_trials={world}"])
+    setup = dict(device=device, dtype=torch.float)
+    attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
+    rec_models, labels, stats = attacker.prepare_attack(case.server_payload, case.shared_data)
+    attacker.objective.initialize(attacker.loss_fn, cfg.impl, None)
+    for reg in attacker.regularizers:
+        reg.initialize(rec_models, case.shared_data, labels)
+    x0 = initial_candidate(case.data_cfg, 1, trial=rank).to(device).requires_grad_(True)
+    run = FusedTrial(attacker, [x0], labels, rec_models, case.shared_data)
+    n_elements = sum(p.numel() for p in rec_models[0].parameters())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        run.step()
+    plan = attacker.objective._plan
+    if plan is not None and not args.no_kernel_timing:
+        plan.enable_timing()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- kernel timing (HIP events recorded on the launch stream during the timed region) -----------------------------
+    roofline = None
+    kernels = {}
+    if plan is not None and plan.timers is not None:
+        for key, bytes_per in (("fwd", 2 * n_elements * 4), ("bwd", 3 * n_elements * 4)):
+            pairs = plan.timers[key]
+            if pairs:
+                ms = sorted(a.elapsed_time(b) for a, b in pairs)
+                avg_ms = sum(ms) / len(ms)
+                kernels[key] = dict(avg_us=avg_ms * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=len(ms),
+                                    algorithmic_bytes=bytes_per, achieved_GBs=bytes_per / (avg_ms * 1e-3) / 1e9)
+        if "fwd" in kernels:
+            k = kernels["fwd"]
+            roofline = dict(bound="hbm", kernel="gm_fwd_kernel<cosine>", achieved=round(k["achieved_GBs"], 1), peak=HBM_PEAK_GBS,
+                            unit="GB/s", frac=round(k["achieved_GBs"] / HBM_PEAK_GBS, 4), traffic=None,
+                            avg_launch_us=round(k["avg_us"], 2), algorithmic_bytes=k["algorithmic_bytes"])
+
+    # ---- trial selection: the one collective of the multi-GPU path --------------------------------------------------
+    select_ms = None
+    state = run.read_state()
+    if world > 1:
+        torch.cuda.synchronize(device)
+        ts = time.perf_counter()
+        shard = trials.TrialShard.current(world)
+        best = run.best()[0]
+        value, _ = shard.select({rank: best}, {rank: state["minimum"]}, stats, device)
+        torch.cuda.synchronize(device)
+        select_ms = (time.perf_counter() - ts) * 1e3
+
+    # ---- CPU baseline (rank 0, N == 1 only) ---------------------------------------------------------------------------
+    cpu_baseline = None
+    if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
+        from oracle import restate
+
+        threads = min(os.cpu_count() or 1, 32)
+        torch.set_num_threads(threads)
+        cpu_case = build_case(args.model, "ImageNet", 1, device="cpu")
+        cpu_cfg = breaching_amd.get_attack_config("invertinggradients")
+        x0_cpu = initial_candidate(cpu_case.data_cfg, 1)
+        restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
+                           initial_data=x0_cpu, max_iterations=2)  # warm-up (allocator, oneDNN primitives)
+        timing = []
+        restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
+                           initial_data=x0_cpu, max_iterations=args.cpu_baseline_iters, timing=timing)
+        cpu_baseline = dict(value=round(args.cpu_baseline_iters / timing[0], 3), unit="attack iterations/s", cores=threads,
+                            kind="port", sample=f"{args.cpu_baseline_iters} iterations of the same ResNet-18/224 invertinggradients "
+                            f"workload through oracle/restate.py (torch {torch.__version__} CPU), after 2 warm-up iterations")
+
+    if rank == 0:
+        line = {
+            "metric": "attack iters/sec, ResNet-18 ImageNet invertinggradients",
+            "value": round(world * args.steps / elapsed, 3),
+            "unit": "attack iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.model} (1000 classes, random init) 1x3x224x224, attack=invertinggradients "
+                                   "(cosine + TV 0.2, hard-sign Adam, boxed), one trial per GPU",
+                       "gradient_list_elements": n_elements, "trials": world, "parallelism": f"trial-parallel x{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "kernels": kernels,
+            "final_objective": state["total"],
+            "select_ms": select_ms,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

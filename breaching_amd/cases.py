@@ -1,0 +1,228 @@
+"""Synthetic attack cases: victim models and the two dictionaries the attacker consumes.
+
+The reference builds these through its case simulation (``cases.construct_model`` model_preparation.py:17-39,
+``HonestServer.distribute_payload`` servers.py:138-147, ``UserSingleStep.compute_local_updates`` users.py:107-186), all
+of which needs datasets on disk.  For the hot path only the *shape* of their output matters:
+
+  server_payload = [dict(parameters=[...], buffers=[...] | None, metadata=<data cfg>)]
+  shared_data    = [dict(gradients=[...], buffers=None | [...], metadata=dict(num_data_points, labels, local_hyperparams))]
+
+Victim models stay plain ``torch.nn`` (PyTorch-ROCm runs their forward / backward / double backward).  The
+architectures are the ones the reference attacks: ``ConvNet`` (model_preparation.py:437-479) and torchvision-shaped
+ResNets (reference class resnets.py:45-237 with stem="standard").  Layer construction and initialisation order follow
+the reference so that the same seed yields bitwise the same parameters (checked against golden checksums in tests).
+"""
+
+import torch
+
+from .config import AttrDict, get_data_config
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# models
+# -----------------------------------------------------------------------------------------------------------------
+class ConvNet(torch.nn.Module):
+    """Eight conv-BN-ReLU stages (widths w,2w,2w,4w,4w,4w | pool | 4w,4w | pool) and a linear head."""
+
+    def __init__(self, width=32, num_classes=10, num_channels=3):
+        super().__init__()
+        plan = [(num_channels, width), (width, 2 * width), (2 * width, 2 * width), (2 * width, 4 * width),
+                (4 * width, 4 * width), (4 * width, 4 * width), "pool", (4 * width, 4 * width), (4 * width, 4 * width),
+                "pool"]
+        layers = []
+        for item in plan:
+            if item == "pool":
+                layers.append(torch.nn.MaxPool2d(3))
+            else:
+                layers += [torch.nn.Conv2d(item[0], item[1], kernel_size=3, padding=1), torch.nn.BatchNorm2d(item[1]),
+                           torch.nn.ReLU()]
+        layers += [torch.nn.Flatten(), torch.nn.Linear(36 * width, num_classes)]
+        self.model = torch.nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.model(x)
+
+
+class _Residual(torch.nn.Module):
+    """Basic (two 3x3) or bottleneck (1x1, 3x3, 1x1) residual unit, torchvision v1.5 stride placement."""
+
+    def __init__(self, inplanes, planes, stride, bottleneck, project):
+        super().__init__()
+        out_planes = planes * (4 if bottleneck else 1)
+        # the projection shortcut is created first (RNG order of the reference's _make_layer), registered last
+        shortcut = None
+        if project:
+            shortcut = torch.nn.Sequential(
+                torch.nn.Conv2d(inplanes, out_planes, kernel_size=1, stride=stride, bias=False),
+                torch.nn.BatchNorm2d(out_planes),
+            )
+        if bottleneck:
+            self.conv1 = torch.nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(planes)
+            self.conv2 = torch.nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+            self.bn2 = torch.nn.BatchNorm2d(planes)
+            self.conv3 = torch.nn.Conv2d(planes, out_planes, kernel_size=1, bias=False)
+            self.bn3 = torch.nn.BatchNorm2d(out_planes)
+        else:
+            self.conv1 = torch.nn.Conv2d(inplanes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+            self.bn1 = torch.nn.BatchNorm2d(planes)
+            self.conv2 = torch.nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
+            self.bn2 = torch.nn.BatchNorm2d(planes)
+        self.bottleneck = bottleneck
+        self.shortcut = shortcut
+
+    def forward(self, x):
+        out = torch.relu(self.bn1(self.conv1(x)))
+        if self.bottleneck:
+            out = torch.relu(self.bn2(self.conv2(out)))
+            out = self.bn3(self.conv3(out))
+        else:
+            out = self.bn2(self.conv2(out))
+        identity = x if self.shortcut is None else self.shortcut(x)
+        return torch.relu(out + identity)
+
+
+class ResNet(torch.nn.Module):
+    """ImageNet ResNet-{18,34,50,101,152}: 7x7/2 stem, 3x3/2 max-pool, four stages, global average pool, linear."""
+
+    _DEPTHS = {18: (False, (2, 2, 2, 2)), 34: (False, (3, 4, 6, 3)), 50: (True, (3, 4, 6, 3)),
+               101: (True, (3, 4, 23, 3)), 152: (True, (3, 8, 36, 3))}
+
+    def __init__(self, depth=18, num_classes=1000, num_channels=3):
+        super().__init__()
+        if depth not in self._DEPTHS:
+            raise ValueError(f"Invalid depth {depth} given.")
+        bottleneck, counts = self._DEPTHS[depth]
+        expansion = 4 if bottleneck else 1
+        self.stem = torch.nn.Sequential(
+            torch.nn.Conv2d(num_channels, 64, kernel_size=7, stride=2, padding=3, bias=False),
+            torch.nn.BatchNorm2d(64), torch.nn.ReLU(), torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1),
+        )
+        stages, inplanes, planes = [], 64, 64
+        for stage, count in enumerate(counts):
+            stride = 1 if stage == 0 else 2
+            units = []
+            for unit in range(count):
+                s = stride if unit == 0 else 1
+                project = unit == 0 and (s != 1 or inplanes != planes * expansion)
+                units.append(_Residual(inplanes, planes, s, bottleneck, project))
+                inplanes = planes * expansion
+            stages.append(torch.nn.Sequential(*units))
+            planes *= 2
+        self.layers = torch.nn.Sequential(*stages)
+        self.avgpool = torch.nn.AdaptiveAvgPool2d((1, 1))
+        self.linear = torch.nn.Linear(inplanes, num_classes)
+        for m in self.modules():  # kaiming-normal(fan_out) convs, unit BN scale (resnets.py:129-134)
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, torch.nn.BatchNorm2d):
+                torch.nn.init.constant_(m.weight, 1)
+                torch.nn.init.constant_(m.bias, 0)
+
+    def forward(self, x):
+        x = self.layers(self.stem(x))
+        return self.linear(torch.flatten(self.avgpool(x), 1))
+
+
+def build_model(name, num_classes, seed=0):
+    """Seeded random-init victim model in eval mode (public BN buffers: mean 0, var 1)."""
+    torch.manual_seed(seed)
+    key = name.lower()
+    if key == "convnet":
+        model = ConvNet(width=64, num_classes=num_classes)
+    elif key.startswith("resnet"):
+        model = ResNet(depth=int(key.replace("resnet", "")), num_classes=num_classes)
+    else:
+        raise ValueError(f"Unknown synthetic victim model {name}.")
+    model.eval()
+    return model
+
+
+def parameter_checksum(model):
+    """Order-sensitive fp64 checksum of all parameters and buffers (pins bitwise equality with the reference's init)."""
+    total = 0.0
+    for i, t in enumerate(list(model.parameters()) + list(model.buffers())):
+        t = t.detach().double().flatten().cpu()
+        if t.numel():
+            total += float((t * torch.linspace(1.0, 2.0, t.numel(), dtype=torch.float64)).sum()) * (1 + 0.001 * i)
+    return total
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# payload / shared data
+# -----------------------------------------------------------------------------------------------------------------
+def synthetic_user_data(data_cfg, num_data_points, seed=1, kind="rand"):
+    """Normalised synthetic images and fixed labels, drawn with a CPU generator so every device sees the same data."""
+    gen = torch.Generator().manual_seed(seed)
+    shape = (num_data_points, *data_cfg.shape)
+    mean = torch.as_tensor(data_cfg.mean)[None, :, None, None]
+    std = torch.as_tensor(data_cfg.std)[None, :, None, None]
+    if kind == "rand":
+        x = (torch.rand(shape, generator=gen) - mean) / std
+    else:
+        x = torch.randn(shape, generator=gen)
+    labels = torch.randint(0, data_cfg.classes, (num_data_points,), generator=gen).sort()[0]
+    return x, labels
+
+
+def initial_candidate(data_cfg, num_data_points, seed=2, trial=0):
+    gen = torch.Generator().manual_seed(seed + trial)
+    return torch.randn((num_data_points, *data_cfg.shape), generator=gen)
+
+
+def honest_payload(model, data_cfg, public_buffers=True):
+    """servers.py:138-147 -- references to the live parameters, public buffers for an honest-but-curious server."""
+    return [dict(parameters=[p for p in model.parameters()],
+                 buffers=[b for b in model.buffers()] if public_buffers else None, metadata=data_cfg)]
+
+
+def single_step_update(model, loss_fn, x, labels, provide_labels=True, provide_buffers=False):
+    """users.py:107-186 for one local step: the plain gradient of the loss on the user's batch."""
+    was_training = model.training
+    if provide_buffers:
+        model.train()
+    loss = loss_fn(model(x), labels)
+    grads = torch.autograd.grad(loss, tuple(model.parameters()))
+    buffers = [b.clone().detach() for b in model.buffers()] if provide_buffers else None
+    model.train(was_training)
+    return [dict(gradients=[g.detach() for g in grads], buffers=buffers,
+                 metadata=dict(num_data_points=x.shape[0], labels=labels if provide_labels else None,
+                               local_hyperparams=None))]
+
+
+def build_case(model_name="convnet", data_name="CIFAR10", num_data_points=1, device="cpu", seed_model=0, seed_data=1,
+               provide_labels=True, provide_buffers=False, classes=None, gradient_device=None):
+    """Everything a parity run needs.  ``gradient_device`` is where the user's gradient is computed (defaults to CPU so
+    that HIP runs and CPU oracle runs observe bitwise the same gradient)."""
+    data_cfg = get_data_config(data_name)
+    if classes is not None:
+        data_cfg.classes = classes
+    model = build_model(model_name, data_cfg.classes, seed_model)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    x_true, labels = synthetic_user_data(data_cfg, num_data_points, seed_data)
+    gdev = torch.device(gradient_device or "cpu")
+    user_model = model.to(gdev)
+    shared = single_step_update(user_model, loss_fn, x_true.to(gdev), labels.to(gdev), provide_labels, provide_buffers)
+    device = torch.device(device)
+    model = model.to(device)
+    for entry in shared:
+        entry["gradients"] = [g.to(device) for g in entry["gradients"]]
+        if entry["buffers"] is not None:
+            entry["buffers"] = [b.to(device) for b in entry["buffers"]]
+        if entry["metadata"]["labels"] is not None:
+            entry["metadata"]["labels"] = entry["metadata"]["labels"].to(device)
+    payload = honest_payload(model, data_cfg, public_buffers=True)
+    return AttrDict(model=model, loss_fn=loss_fn, server_payload=payload, shared_data=shared,
+                    true_user_data=dict(data=x_true, labels=labels), data_cfg=data_cfg)
+
+
+def psnr(reconstruction, truth, data_cfg):
+    """Mean per-example PSNR on de-normalised, clamped images (analysis.py:228-229, metrics.py:122-130, factor=1)."""
+    mean = torch.as_tensor(data_cfg.mean, dtype=torch.float32)[None, :, None, None]
+    std = torch.as_tensor(data_cfg.std, dtype=torch.float32)[None, :, None, None]
+    rec = torch.clamp(reconstruction.detach().float().cpu() * std + mean, 0, 1)
+    ref = torch.clamp(truth.detach().float().cpu() * std + mean, 0, 1)
+    mse = ((rec - ref) ** 2).reshape(rec.shape[0], -1).mean(dim=1)
+    if bool((mse == 0).any()):
+        return float("inf")
+    return float((10 * torch.log10(1.0 / mse)).mean())

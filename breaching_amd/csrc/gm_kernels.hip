@@ -1,0 +1,447 @@
+// Kernel A: gradient-matching reductions over a per-parameter gradient list, forward and backward.
+//
+// Replaces the TorchScript list loops of breaching/attacks/auxiliaries/objectives.py
+// (:89-95 Euclidean, :133-141 EuclideanTag, :158-166 L1, :183-196 Cosine, :233-244 masked, :259-273 fast) -- about
+// 1.5k tiny ATen launches per attack iteration for ResNet-18 -- by ONE multi-tensor launch per direction.
+//
+// Layout: the autograd gradients arrive as T separately allocated tensors whose addresses may change every
+// iteration, so their base pointers travel in the kernel-argument segment (no device table to refresh, no copy,
+// graph-capture friendly).  The observed gradient and the output gradient live in packed flat buffers.  Work is
+// cut into chunks of BH_GM_CHUNK elements that never straddle a tensor; one 256-thread workgroup streams one chunk
+// with 16-byte loads (4 per thread per operand in flight), reduces with wave64 shuffles + LDS and writes one row of
+// fp64 partial sums.  A single-workgroup finalize kernel combines the rows in a fixed order.
+//
+// Roofline: HBM-bound, 2*N*4 bytes forward, 3*N*4 bytes backward (N = total elements).  No MFMA: <= 2 flop/byte.
+
+#include "bh_common.h"
+
+namespace {
+
+using bh::kBlock;
+
+struct GmPtrs {
+  const float* p[BH_GM_MAX_PTRS];
+};
+
+constexpr int kVecPerThread = BH_GM_CHUNK / 4 / kBlock;  // float4 loads per thread per operand for a full chunk
+static_assert(BH_GM_CHUNK % (4 * kBlock) == 0, "chunk must be a whole number of float4 sweeps");
+
+constexpr bool is_cosine_family(int kind) { return kind <= BH_GM_ANGULAR; }
+
+template <int KIND>
+__device__ __forceinline__ void accumulate(float r, float d, float& a0, float& a1, float& a2) {
+  if constexpr (KIND == BH_GM_COSINE_MASKED) {
+    const bool keep = fabsf(d) > 1e-6f;  // objectives.py:236
+    r = keep ? r : 0.f;
+    d = keep ? d : 0.f;
+  }
+  if constexpr (is_cosine_family(KIND)) {
+    a0 = fmaf(r, d, a0);
+    a1 = fmaf(r, r, a1);
+    a2 = fmaf(d, d, a2);
+  } else {
+    const float e = r - d;
+    if constexpr (KIND != BH_GM_L1) a0 = fmaf(e, e, a0);
+    if constexpr (KIND != BH_GM_L2) a1 += fabsf(e);
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void accumulate4(const float4& r, const float4& d, float& a0, float& a1, float& a2) {
+  accumulate<KIND>(r.x, d.x, a0, a1, a2);
+  accumulate<KIND>(r.y, d.y, a0, a1, a2);
+  accumulate<KIND>(r.z, d.z, a0, a1, a2);
+  accumulate<KIND>(r.w, d.w, a0, a1, a2);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
+                                                        const bh_gm_chunk* __restrict__ chunks, int chunk_base,
+                                                        const float* __restrict__ weights, float tag_scale,
+                                                        double* __restrict__ partials) {
+  __shared__ double lds[bh::kWavesPerBlock * 3];
+  const int c = chunk_base + blockIdx.x;
+  const bh_gm_chunk ch = chunks[c];
+  const float* __restrict__ r = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
+  const float* __restrict__ d = data_flat + ch.flat_off;
+  const int tid = threadIdx.x;
+
+  // two independent accumulator sets keep the fma chains short
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(r);
+  const float4* __restrict__ d4 = reinterpret_cast<const float4*>(d);
+  if (ch.len == BH_GM_CHUNK) {
+    float4 rv[kVecPerThread], dv[kVecPerThread];
+#pragma unroll
+    for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
+#pragma unroll
+    for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
+#pragma unroll
+    for (int k = 0; k < kVecPerThread; k += 2) {
+      accumulate4<KIND>(rv[k], dv[k], a0, a1, a2);
+      if (k + 1 < kVecPerThread) accumulate4<KIND>(rv[k + 1], dv[k + 1], b0, b1, b2);
+    }
+  } else {
+    const int n4 = ch.len >> 2;
+    for (int i = tid; i < n4; i += kBlock) accumulate4<KIND>(r4[i], d4[i], a0, a1, a2);
+    const int tail = ch.len & 3;
+    if (tid < tail) accumulate<KIND>(r[(n4 << 2) + tid], d[(n4 << 2) + tid], b0, b1, b2);
+  }
+  double v[3] = {(double)a0 + (double)b0, (double)a1 + (double)b1, (double)a2 + (double)b2};
+  bh::block_sum<3>(v, lds);
+  if (tid == 0) {
+    double* row = partials + (int64_t)c * BH_GM_PARTIAL_STRIDE;
+    if constexpr (KIND == BH_GM_TAG) {
+      // objectives.py:139-140: (rec-data).pow(2).sum() + tag_scale * weight * (rec-data).abs().sum()
+      const double w = (double)tag_scale * (double)weights[ch.tensor];
+      row[0] = v[0] + w * v[1];
+    } else {
+      row[0] = v[0];
+    }
+    row[1] = v[1];
+    row[2] = v[2];
+  }
+}
+
+// Single workgroup: fixed-order sum of the partial rows, then the objective epilogue.
+__global__ __launch_bounds__(kBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials, int64_t n_rows,
+                                                             float scale, float tag_scale, float fudge,
+                                                             float* __restrict__ stats) {
+  __shared__ double lds[bh::kWavesPerBlock * 3];
+  double v[3] = {0.0, 0.0, 0.0};
+  for (int64_t row = threadIdx.x; row < n_rows; row += kBlock) {
+    const double* p = partials + row * BH_GM_PARTIAL_STRIDE;
+    v[0] += p[0];
+    v[1] += p[1];
+    v[2] += p[2];
+  }
+  bh::block_sum<3>(v, lds);
+  if (threadIdx.x != 0) return;
+  const double s = (double)scale;
+  double loss = 0.0, c1 = 0.0, c2 = 0.0;
+  if (kind <= BH_GM_ANGULAR) {
+    const double dot = v[0], rr = v[1], dd = v[2];
+    const double rn = sqrt(rr), dn = sqrt(dd);
+    const double inv = 1.0 / (rn * dn);
+    const double cosv = dot * inv;
+    // d cos / d r = d * inv - r * dot / (rr * rn * dn)
+    const double dcos_d = inv;
+    const double dcos_r = -dot * inv / rr;
+    if (kind == BH_GM_ANGULAR) {
+      // objectives.py:210-214: acos(clamp(cos, -1+f, 1-f)) / pi * scale
+      const double lo = -1.0 + (double)fudge, hi = 1.0 - (double)fudge;
+      const bool clamped = !(cosv > lo && cosv < hi);
+      const double cc = cosv < lo ? lo : (cosv > hi ? hi : cosv);
+      const double pi = 3.14159265358979323846;
+      loss = s * acos(cc) / pi;
+      const double dl = clamped ? 0.0 : -s / (pi * sqrt(1.0 - cc * cc));
+      c1 = dl * dcos_d;
+      c2 = dl * dcos_r;
+    } else {
+      loss = s * (1.0 - cosv);  // objectives.py:195
+      c1 = -s * dcos_d;
+      c2 = (kind == BH_GM_COSINE_FAST) ? 0.0 : -s * dcos_r;  // fast variant: norms detached (:268-269)
+    }
+  } else if (kind == BH_GM_L2) {
+    loss = s * 0.5 * v[0];  // objectives.py:95
+    c1 = s;
+  } else if (kind == BH_GM_L1) {
+    loss = s * 0.5 * v[1];  // objectives.py:166
+    c2 = 0.5 * s;
+  } else {  // BH_GM_TAG
+    loss = s * 0.5 * v[0];  // objectives.py:141
+    c1 = s;
+    c2 = 0.5 * s * (double)tag_scale;
+  }
+  stats[BH_GM_STAT_LOSS] = (float)loss;
+  stats[BH_GM_STAT_C1] = (float)c1;
+  stats[BH_GM_STAT_C2] = (float)c2;
+  stats[BH_GM_STAT_S0] = (float)v[0];
+  stats[BH_GM_STAT_S1] = (float)v[1];
+  stats[BH_GM_STAT_S2] = (float)v[2];
+  stats[6] = 0.f;
+  stats[7] = 0.f;
+}
+
+template <int KIND>
+__device__ __forceinline__ float bwd_elem(float r, float d, float k1, float k2) {
+  if constexpr (is_cosine_family(KIND)) {
+    float o = fmaf(k1, d, k2 * r);
+    if constexpr (KIND == BH_GM_COSINE_MASKED) o = (fabsf(d) > 1e-6f) ? o : 0.f;
+    return o;
+  } else {
+    const float e = r - d;
+    if constexpr (KIND == BH_GM_L2) return k1 * e;
+    if constexpr (KIND == BH_GM_L1) return k2 * bh::sgnf(e);
+    return fmaf(k1, e, k2 * bh::sgnf(e));
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ float4 bwd_elem4(const float4& r, const float4& d, float k1, float k2) {
+  return make_float4(bwd_elem<KIND>(r.x, d.x, k1, k2), bwd_elem<KIND>(r.y, d.y, k1, k2),
+                     bwd_elem<KIND>(r.z, d.z, k1, k2), bwd_elem<KIND>(r.w, d.w, k1, k2));
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void gm_bwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
+                                                        const bh_gm_chunk* __restrict__ chunks, int chunk_base,
+                                                        const float* __restrict__ weights,
+                                                        const float* __restrict__ stats, const float* __restrict__ gout,
+                                                        float* __restrict__ grad_flat) {
+  const int c = chunk_base + blockIdx.x;
+  const bh_gm_chunk ch = chunks[c];
+  const float* __restrict__ r = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
+  const float* __restrict__ d = data_flat + ch.flat_off;
+  float* __restrict__ o = grad_flat + ch.flat_off;
+  const float g = gout ? gout[0] : 1.f;
+  const float k1 = g * stats[BH_GM_STAT_C1];
+  float k2 = g * stats[BH_GM_STAT_C2];
+  if constexpr (KIND == BH_GM_TAG) k2 *= weights[ch.tensor];
+  const int tid = threadIdx.x;
+  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(r);
+  const float4* __restrict__ d4 = reinterpret_cast<const float4*>(d);
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
+  if (ch.len == BH_GM_CHUNK) {
+    float4 rv[kVecPerThread], dv[kVecPerThread];
+#pragma unroll
+    for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
+#pragma unroll
+    for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
+#pragma unroll
+    for (int k = 0; k < kVecPerThread; ++k) o4[tid + k * kBlock] = bwd_elem4<KIND>(rv[k], dv[k], k1, k2);
+  } else {
+    const int n4 = ch.len >> 2;
+    for (int i = tid; i < n4; i += kBlock) o4[i] = bwd_elem4<KIND>(r4[i], d4[i], k1, k2);
+    const int tail = ch.len & 3;
+    if (tid < tail) {
+      const int i = (n4 << 2) + tid;
+      o[i] = bwd_elem<KIND>(r[i], d[i], k1, k2);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void gm_pack_kernel(GmPtrs ptrs, int tensor_base,
+                                                         const bh_gm_chunk* __restrict__ chunks, int chunk_base,
+                                                         float* __restrict__ flat_dst) {
+  const int c = chunk_base + blockIdx.x;
+  const bh_gm_chunk ch = chunks[c];
+  const float* __restrict__ s = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
+  float* __restrict__ o = flat_dst + ch.flat_off;
+  const int n4 = ch.len >> 2;
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(s);
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
+  for (int i = threadIdx.x; i < n4; i += kBlock) o4[i] = s4[i];
+  const int tail = ch.len & 3;
+  if ((int)threadIdx.x < tail) o[(n4 << 2) + threadIdx.x] = s[(n4 << 2) + threadIdx.x];
+  // zero the alignment padding behind the last chunk of a tensor so the flat buffer is fully defined
+  if (ch.len != BH_GM_CHUNK) {
+    const int pad = (4 - (ch.len & 3)) & 3;
+    if ((int)threadIdx.x < pad) o[ch.len + threadIdx.x] = 0.f;
+  }
+}
+
+bool valid_kind(int kind) { return kind >= BH_GM_COSINE && kind <= BH_GM_TAG; }
+
+// Fill the kernarg pointer block for launch group `g`; returns false on a misaligned / null pointer.
+bool fill_ptrs(GmPtrs& out, const void* const* ptrs, int n_tensors, int g) {
+  const int base = g * BH_GM_MAX_PTRS;
+  const int cnt = (n_tensors - base) < BH_GM_MAX_PTRS ? (n_tensors - base) : BH_GM_MAX_PTRS;
+  for (int i = 0; i < cnt; ++i) {
+    const void* p = ptrs[base + i];
+    if (p == nullptr || (reinterpret_cast<uintptr_t>(p) & 15u) != 0) return false;
+    out.p[i] = static_cast<const float*>(p);
+  }
+  for (int i = cnt; i < BH_GM_MAX_PTRS; ++i) out.p[i] = nullptr;
+  return true;
+}
+
+bool aligned16(const void* p) { return p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <int KIND>
+void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
+                int n, const float* weights, float tag_scale, double* partials, hipStream_t st) {
+  hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+                     chunk_base, weights, tag_scale, partials);
+}
+
+template <int KIND>
+void launch_bwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
+                int n, const float* weights, const float* stats, const float* gout, float* grad_flat, hipStream_t st) {
+  hipLaunchKernelGGL(gm_bwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+                     chunk_base, weights, stats, gout, grad_flat);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t bh_gm_num_groups(int32_t n_tensors) {
+  return n_tensors <= 0 ? 0 : (n_tensors + BH_GM_MAX_PTRS - 1) / BH_GM_MAX_PTRS;
+}
+
+int bh_gm_table_size(int32_t n_tensors, const int64_t* numel, int64_t* n_chunks, int64_t* flat_elems) {
+  if (n_tensors < 0 || (n_tensors > 0 && numel == nullptr) || n_chunks == nullptr || flat_elems == nullptr)
+    return BH_EINVAL;
+  int64_t chunks = 0, flat = 0;
+  for (int32_t t = 0; t < n_tensors; ++t) {
+    if (numel[t] < 0) return BH_EINVAL;
+    chunks += (numel[t] + BH_GM_CHUNK - 1) / BH_GM_CHUNK;
+    flat += (numel[t] + 3) & ~int64_t(3);
+  }
+  if (chunks > INT32_MAX) return BH_EINVAL;
+  *n_chunks = chunks;
+  *flat_elems = flat;
+  return 0;
+}
+
+int bh_gm_build_table(int32_t n_tensors, const int64_t* numel, bh_gm_chunk* chunks, int64_t n_chunks,
+                      int64_t* tensor_flat_off) {
+  int64_t need = 0, flat_total = 0;
+  int rc = bh_gm_table_size(n_tensors, numel, &need, &flat_total);
+  if (rc != 0) return rc;
+  if (need != n_chunks || (n_chunks > 0 && chunks == nullptr) || (n_tensors > 0 && tensor_flat_off == nullptr))
+    return BH_EINVAL;
+  int64_t c = 0, flat = 0;
+  for (int32_t t = 0; t < n_tensors; ++t) {
+    tensor_flat_off[t] = flat;
+    for (int64_t off = 0; off < numel[t]; off += BH_GM_CHUNK) {
+      const int64_t len = (numel[t] - off) < BH_GM_CHUNK ? (numel[t] - off) : BH_GM_CHUNK;
+      chunks[c].flat_off = flat + off;
+      chunks[c].tensor_off = off;
+      chunks[c].tensor = t;
+      chunks[c].len = (int32_t)len;
+      ++c;
+    }
+    flat += (numel[t] + 3) & ~int64_t(3);
+  }
+  return 0;
+}
+
+int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_t n_chunks,
+                       int32_t* group_chunk_begin) {
+  if (n_tensors < 0 || n_chunks < 0 || group_chunk_begin == nullptr || (n_chunks > 0 && chunks_host == nullptr))
+    return BH_EINVAL;
+  const int groups = bh_gm_num_groups(n_tensors);
+  int64_t c = 0;
+  for (int g = 0; g < groups; ++g) {
+    while (c < n_chunks && chunks_host[c].tensor < g * BH_GM_MAX_PTRS) ++c;
+    group_chunk_begin[g] = (int32_t)c;
+  }
+  group_chunk_begin[groups] = (int32_t)n_chunks;
+  return 0;
+}
+
+int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
+              const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
+              const float* weights_dev, float tag_scale, double* partials_dev, void* stream) {
+  if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
+      n_chunks <= 0 || group_chunk_begin == nullptr || partials_dev == nullptr)
+    return BH_EINVAL;
+  if (kind == BH_GM_TAG && weights_dev == nullptr) return BH_EINVAL;
+  hipStream_t st = bh::as_stream(stream);
+  const int groups = bh_gm_num_groups(n_tensors);
+  for (int g = 0; g < groups; ++g) {
+    const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
+    if (n <= 0) continue;
+    GmPtrs ptrs;
+    if (!fill_ptrs(ptrs, rec_ptrs, n_tensors, g)) return BH_EINVAL;
+    const int tb = g * BH_GM_MAX_PTRS;
+    switch (kind) {
+      case BH_GM_COSINE:
+      case BH_GM_COSINE_FAST:
+      case BH_GM_ANGULAR:
+        launch_fwd<BH_GM_COSINE>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        break;
+      case BH_GM_COSINE_MASKED:
+        launch_fwd<BH_GM_COSINE_MASKED>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev,
+                                        st);
+        break;
+      case BH_GM_L2:
+        launch_fwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        break;
+      case BH_GM_L1:
+        launch_fwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        break;
+      default:
+        launch_fwd<BH_GM_TAG>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        break;
+    }
+    const int rc = bh::launch_status();
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
+                   float* stats_dev, void* stream) {
+  if (!valid_kind(kind) || partials_dev == nullptr || n_rows <= 0 || stats_dev == nullptr) return BH_EINVAL;
+  hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), kind, partials_dev, n_rows,
+                     scale, tag_scale, fudge, stats_dev);
+  return bh::launch_status();
+}
+
+int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
+              const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
+              const float* weights_dev, const float* stats_dev, const float* gout_dev, float* grad_flat, void* stream) {
+  if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
+      n_chunks <= 0 || group_chunk_begin == nullptr || stats_dev == nullptr || !aligned16(grad_flat))
+    return BH_EINVAL;
+  if (kind == BH_GM_TAG && weights_dev == nullptr) return BH_EINVAL;
+  hipStream_t st = bh::as_stream(stream);
+  const int groups = bh_gm_num_groups(n_tensors);
+  for (int g = 0; g < groups; ++g) {
+    const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
+    if (n <= 0) continue;
+    GmPtrs ptrs;
+    if (!fill_ptrs(ptrs, rec_ptrs, n_tensors, g)) return BH_EINVAL;
+    const int tb = g * BH_GM_MAX_PTRS;
+    switch (kind) {
+      case BH_GM_COSINE:
+      case BH_GM_COSINE_FAST:
+      case BH_GM_ANGULAR:
+        launch_bwd<BH_GM_COSINE>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat,
+                                 st);
+        break;
+      case BH_GM_COSINE_MASKED:
+        launch_bwd<BH_GM_COSINE_MASKED>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev,
+                                        grad_flat, st);
+        break;
+      case BH_GM_L2:
+        launch_bwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st);
+        break;
+      case BH_GM_L1:
+        launch_bwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st);
+        break;
+      default:
+        launch_bwd<BH_GM_TAG>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat,
+                              st);
+        break;
+    }
+    const int rc = bh::launch_status();
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+int bh_gm_pack(int32_t n_tensors, const void* const* src_ptrs, const bh_gm_chunk* chunks_dev, int64_t n_chunks,
+               const int32_t* group_chunk_begin, float* flat_dst, void* stream) {
+  if (n_tensors <= 0 || src_ptrs == nullptr || chunks_dev == nullptr || n_chunks <= 0 || group_chunk_begin == nullptr ||
+      !aligned16(flat_dst))
+    return BH_EINVAL;
+  hipStream_t st = bh::as_stream(stream);
+  const int groups = bh_gm_num_groups(n_tensors);
+  for (int g = 0; g < groups; ++g) {
+    const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
+    if (n <= 0) continue;
+    GmPtrs ptrs;
+    if (!fill_ptrs(ptrs, src_ptrs, n_tensors, g)) return BH_EINVAL;
+    hipLaunchKernelGGL(gm_pack_kernel, dim3(n), dim3(kBlock), 0, st, ptrs, g * BH_GM_MAX_PTRS, chunks_dev, begin,
+                       flat_dst);
+    const int rc = bh::launch_status();
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// Kernel B and friends: per-trial device state, loss commit, and the fused candidate step.
+//
+// The reference loop (breaching/attacks/optimization_based_attack.py:110-138) spends three host synchronisations
+// per iteration (`objective_value < minimal_value_so_far` :119, `torch.isfinite` :131, `.item()` :135) and ~15 tiny
+// launches for grad post-processing + torch.optim.Adam + projection.  Here the iteration counter, the loss history,
+// the best-so-far bookkeeping and the non-finite flag live in a small device record, and one elementwise kernel does
+//   assemble gradient -> Langevin noise -> norm clip -> sign -> Adam/AdamW -> box projection -> conditional best copy.
+// The host never has to look at the device between callbacks, so the whole iteration can be captured in a hipGraph.
+
+#include "bh_common.h"
+
+namespace {
+
+using bh::kBlock;
+
+union Word {
+  int32_t i;
+  float f;
+};
+
+__global__ void state_reset_kernel(Word* st) {
+  const int t = threadIdx.x;
+  if (t >= BH_STATE_WORDS) return;
+  Word w;
+  w.i = 0;
+  if (t == BH_STATE_IT || t == BH_STATE_FIRST_BAD) w.i = -1;
+  if (t == BH_STATE_MIN) w.f = __builtin_inff();
+  st[t] = w;
+}
+
+// Single workgroup.  Sums the regulariser partials in a fixed order, adds the optional scalar terms, commits.
+__global__ __launch_bounds__(kBlock) void loss_commit_kernel(Word* __restrict__ st, float* __restrict__ history,
+                                                             int history_len, const float* __restrict__ gm_loss,
+                                                             const double* __restrict__ reg_partials, int n_reg,
+                                                             const float* __restrict__ extra0,
+                                                             const float* __restrict__ extra1) {
+  __shared__ double lds[bh::kWavesPerBlock];
+  double v[1] = {0.0};
+  for (int i = threadIdx.x; i < n_reg; i += kBlock) v[0] += reg_partials[i];
+  bh::block_sum<1>(v, lds);
+  if (threadIdx.x != 0) return;
+  // reference order: objective, then regularisers (optimization_based_attack.py:157-162), all fp32 adds
+  float total = gm_loss ? gm_loss[0] : 0.f;
+  if (n_reg > 0) total += (float)v[0];
+  if (extra0) total += extra0[0];
+  if (extra1) total += extra1[0];
+  const int it = st[BH_STATE_IT].i + 1;
+  st[BH_STATE_IT].i = it;
+  st[BH_STATE_TOTAL].f = total;
+  if (it >= 0 && it < history_len) history[it] = total;
+  const bool dead = st[BH_STATE_DEAD].i != 0;
+  const bool improved = !dead && (total < st[BH_STATE_MIN].f);  // :119 (false for NaN)
+  st[BH_STATE_IMPROVED].i = improved ? 1 : 0;
+  if (improved) st[BH_STATE_MIN].f = total;
+  if (!dead && !isfinite(total)) {  // :131-133 -- the reference leaves the loop here
+    st[BH_STATE_DEAD].i = 1;
+    st[BH_STATE_FIRST_BAD].i = it;
+  }
+}
+
+__device__ __forceinline__ float effective_grad(const float* __restrict__ g, const float* __restrict__ g_reg,
+                                                const float* __restrict__ noise, float noise_coef, int64_t i) {
+  float v = g[i];
+  if (g_reg) v += g_reg[i];
+  if (noise) v = fmaf(noise_coef, noise[i], v);  // optimization_based_attack.py:167-170
+  return v;
+}
+
+__global__ __launch_bounds__(kBlock) void grad_sumsq_kernel(const Word* __restrict__ st, const float* __restrict__ g,
+                                                            const float* __restrict__ g_reg,
+                                                            const float* __restrict__ noise, int64_t n,
+                                                            const double* __restrict__ sched, float langevin,
+                                                            double* __restrict__ ws) {
+  __shared__ double lds[bh::kWavesPerBlock];
+  const int it = st[BH_STATE_IT].i;
+  const float noise_coef = noise ? (float)((double)langevin * sched[(int64_t)it * BH_SCHED_STRIDE + 3]) : 0.f;
+  float acc = 0.f;
+  double dacc = 0.0;
+  int cnt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const float v = effective_grad(g, g_reg, noise, noise_coef, i);
+    acc = fmaf(v, v, acc);
+    if (++cnt == 32) {
+      dacc += (double)acc;
+      acc = 0.f;
+      cnt = 0;
+    }
+  }
+  double v[1] = {dacc + (double)acc};
+  bh::block_sum<1>(v, lds);
+  if (threadIdx.x == 0) ws[blockIdx.x] = v[0];
+}
+
+__global__ __launch_bounds__(kBlock) void grad_norm_finalize_kernel(Word* __restrict__ st, const double* __restrict__ ws,
+                                                                    int rows) {
+  __shared__ double lds[bh::kWavesPerBlock];
+  double v[1] = {0.0};
+  for (int i = threadIdx.x; i < rows; i += kBlock) v[0] += ws[i];
+  bh::block_sum<1>(v, lds);
+  if (threadIdx.x == 0) st[BH_STATE_GNORM].f = (float)sqrt(v[0]);
+}
+
+// The fused step.  fp32 arithmetic follows torch.optim's single-tensor Adam update term by term:
+//   exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
+//   denom = (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps); param.addcdiv_(exp_avg, denom, value=-lr/bc1)
+__global__ __launch_bounds__(kBlock) void candidate_step_kernel(const Word* __restrict__ st, const double* __restrict__ sched,
+                                                                bh_step_params P, float* __restrict__ x,
+                                                                const float* __restrict__ g,
+                                                                const float* __restrict__ g_reg,
+                                                                const float* __restrict__ noise, float* __restrict__ m,
+                                                                float* __restrict__ v, float* __restrict__ best) {
+  const int it = st[BH_STATE_IT].i;
+  const bool improved = st[BH_STATE_IMPROVED].i != 0;
+  const double* row = sched + (int64_t)it * BH_SCHED_STRIDE;
+  const float step_size = (float)row[0];
+  const float bc2_sqrt = (float)row[1];
+  const float decay = (float)row[2];
+  const float noise_coef = noise ? (float)((double)P.langevin * row[3]) : 0.f;
+  float clip_mul = 1.f;
+  if (P.grad_clip > 0.f) {
+    const float gn = st[BH_STATE_GNORM].f;
+    if (gn > P.grad_clip) clip_mul = P.grad_clip / (gn + 1e-6f);  // :173-174
+  }
+  // soft sign factor (:176-180): python evaluates 1 - iteration / max_iterations in double
+  const float soft = (float)(1.0 - (double)it / (double)P.max_iterations);
+  const float w1 = (float)(1.0 - (double)P.beta1);
+  const float w2 = (float)(1.0 - (double)P.beta2);
+
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * kBlock) {
+    float gr = effective_grad(g, g_reg, noise, noise_coef, i);
+    gr *= clip_mul;
+    if (P.sign_mode == BH_SIGN_HARD) {
+      gr = bh::sgnf(gr);  // :181-182
+    } else if (P.sign_mode == BH_SIGN_SOFT) {
+      gr = tanhf(gr * soft) / soft;  // :180
+    }
+    float xi = x[i], mi = m[i], vi = v[i];
+    if (P.decoupled_wd) xi *= decay;
+    mi = fmaf(w1, gr - mi, mi);
+    vi = fmaf(w2 * gr, gr, vi * P.beta2);
+    const float denom = sqrtf(vi) / bc2_sqrt + P.eps;
+    xi = xi - (step_size * mi) / denom;
+    if (P.boxed) {  // :117-118  max(min(x, hi), lo)
+      const int c = (int)((i / P.plane) % P.channels);
+      // torch.min / torch.max propagate NaN, fminf / fmaxf would swallow it
+      xi = (xi != xi) ? xi : fmaxf(fminf(xi, P.hi[c]), P.lo[c]);
+    }
+    x[i] = xi;
+    m[i] = mi;
+    v[i] = vi;
+    if (improved) best[i] = xi;  // :119-121 (clone taken after step + projection)
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int bh_state_reset(void* state_dev, void* stream) {
+  if (state_dev == nullptr) return BH_EINVAL;
+  hipLaunchKernelGGL(state_reset_kernel, dim3(1), dim3(64), 0, bh::as_stream(stream), static_cast<Word*>(state_dev));
+  return bh::launch_status();
+}
+
+int bh_loss_commit(void* state_dev, float* history_dev, int32_t history_len, const float* gm_loss,
+                   const double* reg_partials, int32_t n_reg, const float* extra0, const float* extra1, void* stream) {
+  if (state_dev == nullptr || history_len < 0 || (history_len > 0 && history_dev == nullptr) || n_reg < 0 ||
+      (n_reg > 0 && reg_partials == nullptr))
+    return BH_EINVAL;
+  hipLaunchKernelGGL(loss_commit_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), static_cast<Word*>(state_dev),
+                     history_dev, history_len, gm_loss, reg_partials, n_reg, extra0, extra1);
+  return bh::launch_status();
+}
+
+int bh_grad_norm(void* state_dev, const float* g, const float* g_reg, const float* noise, int64_t n,
+                 const double* sched_dev, float langevin, double* ws_dev, void* stream) {
+  if (state_dev == nullptr || g == nullptr || n <= 0 || ws_dev == nullptr || (noise != nullptr && sched_dev == nullptr))
+    return BH_EINVAL;
+  int64_t blocks = (n + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+  if (blocks > BH_PRIOR_MAX_GRID) blocks = BH_PRIOR_MAX_GRID;
+  if (blocks < 1) blocks = 1;
+  hipStream_t st = bh::as_stream(stream);
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3((int)blocks), dim3(kBlock), 0, st, static_cast<const Word*>(state_dev), g,
+                     g_reg, noise, n, sched_dev, langevin, ws_dev);
+  int rc = bh::launch_status();
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(kBlock), 0, st, static_cast<Word*>(state_dev), ws_dev,
+                     (int)blocks);
+  return bh::launch_status();
+}
+
+int bh_candidate_step(const void* state_dev, const double* sched_dev, const bh_step_params* params, float* x,
+                      const float* g, const float* g_reg, const float* noise, float* m, float* v, float* best,
+                      void* stream) {
+  if (state_dev == nullptr || sched_dev == nullptr || params == nullptr || x == nullptr || g == nullptr ||
+      m == nullptr || v == nullptr || best == nullptr)
+    return BH_EINVAL;
+  const bh_step_params& P = *params;
+  if (P.n <= 0 || P.max_iterations <= 0) return BH_EINVAL;
+  if (P.boxed && (P.channels <= 0 || P.channels > 4 || P.plane <= 0)) return BH_EINVAL;
+  if (P.langevin > 0.f && noise == nullptr) return BH_EINVAL;
+  if (P.sign_mode < BH_SIGN_NONE || P.sign_mode > BH_SIGN_SOFT) return BH_EINVAL;
+  int64_t blocks = (P.n + kBlock - 1) / kBlock;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(candidate_step_kernel, dim3((int)blocks), dim3(kBlock), 0, bh::as_stream(stream),
+                     static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, P.langevin > 0.f ? noise : nullptr,
+                     m, v, best);
+  return bh::launch_status();
+}
+
+int32_t bh_abi_version(void) { return BH_ABI_VERSION; }
+
+const char* bh_build_arch(void) { return "gfx950"; }
+
+}  // extern "C"

@@ -1,0 +1,386 @@
+"""Gradient-matching objectives on the HIP kernels (kernel A), behind the reference's objective interface.
+
+reference: breaching/attacks/auxiliaries/objectives.py
+  * ``GradientLoss`` (:9-72): ``initialize(loss_fn, cfg_impl, local_hyperparams)`` and
+    ``forward(model, gradient_data, candidate, labels) -> (objective, task_loss.detach())``
+  * the list reductions ``Euclidean`` :75-95, ``EuclideanTag`` :98-141, ``L1Loss`` :144-166, ``CosineSimilarity``
+    :169-196, ``AngularSimilarity`` :199-217, ``MaskedCosineSimilarity`` :220-244, ``FastCosineSimilarity`` :247-276
+  * ``objective_lookup`` :496-506
+
+The victim model's forward / backward / double backward stay on PyTorch-ROCm; only the reduction over the
+per-parameter gradient list and its derivative run here.
+"""
+
+import ctypes
+from ctypes import c_int32, c_int64, c_void_p
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} lives on {t.device}; the HIP gradient-matching path needs tensors on a ROCm device "
+            "(there is no CPU fallback)."
+        )
+
+
+class GradientMatchPlan:
+    """Static state for one (observed gradient list, objective) pair: chunk table, packed data, launch bounds.
+
+    Built once per attack (reference keeps the Python list, base_attack.py:214-220); pairs beyond the shorter list are
+    dropped like ``zip`` does at objectives.py:190.
+    """
+
+    def __init__(self, gradient_data, n_pairs=None):
+        lib = _lib.load()
+        tensors = list(gradient_data)
+        if n_pairs is not None:
+            tensors = tensors[:n_pairs]
+        if len(tensors) == 0:
+            raise ValueError("Gradient matching needs at least one gradient tensor.")
+        for t in tensors:
+            _require_cuda(t, "observed gradient")
+            if t.dtype != torch.float32:
+                raise NotImplementedError(f"HIP gradient matching computes in fp32; got {t.dtype} (impl.dtype must be float).")
+        self.device = tensors[0].device
+        self.n_tensors = len(tensors)
+        self.shapes = [tuple(t.shape) for t in tensors]
+        self.numels = [t.numel() for t in tensors]
+        self.total_elements = sum(self.numels)
+
+        numel_arr = (c_int64 * self.n_tensors)(*self.numels)
+        n_chunks, flat_elems = c_int64(0), c_int64(0)
+        _lib.check(lib.bh_gm_table_size(self.n_tensors, numel_arr, ctypes.byref(n_chunks), ctypes.byref(flat_elems)), "bh_gm_table_size")
+        self.n_chunks, self.flat_elems = n_chunks.value, flat_elems.value
+        if self.n_chunks == 0:
+            raise ValueError("Gradient list holds no elements.")
+        self._chunks_host = (_lib.GmChunk * self.n_chunks)()
+        flat_off = (c_int64 * self.n_tensors)()
+        _lib.check(lib.bh_gm_build_table(self.n_tensors, numel_arr, self._chunks_host, self.n_chunks, flat_off), "bh_gm_build_table")
+        self.flat_offsets = list(flat_off)
+        n_groups = lib.bh_gm_num_groups(self.n_tensors)
+        self._group_bounds = (c_int32 * (n_groups + 1))()
+        _lib.check(lib.bh_gm_group_bounds(self.n_tensors, self._chunks_host, self.n_chunks, self._group_bounds), "bh_gm_group_bounds")
+
+        # device copies
+        raw = torch.frombuffer(bytearray(bytes(self._chunks_host)), dtype=torch.uint8)
+        self.chunks_dev = raw.to(self.device)
+        self.data_flat = torch.empty(max(self.flat_elems, 4), dtype=torch.float32, device=self.device)
+        self.partials = torch.empty(self.n_chunks * _lib.BH_GM_PARTIAL_STRIDE, dtype=torch.float64, device=self.device)
+        self._dummy = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self._data_ptr_key = tuple(t.data_ptr() for t in tensors[:4])
+        with torch.cuda.device(self.device):
+            srcs = self._pointer_array(tensors)
+            _lib.check(
+                lib.bh_gm_pack(self.n_tensors, srcs, _lib.ptr(self.chunks_dev), self.n_chunks, self._group_bounds,
+                               _lib.ptr(self.data_flat), _lib.current_stream_handle(self.device)),
+                "bh_gm_pack",
+            )
+        self._keepalive = None
+        # optional per-launch timing (bench.py): lists of (start, end) torch.cuda.Event pairs on the launch stream
+        self.timers = None
+
+    def enable_timing(self):
+        self.timers = dict(fwd=[], bwd=[])
+
+    def _timed(self, key):
+        if self.timers is None:
+            return None
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.timers[key].append(pair)
+        return pair
+
+    # -- helpers ---------------------------------------------------------------------------------------------------
+    def _prepare(self, tensors):
+        """Contiguous, 16-byte aligned fp32 views of this iteration's gradients (copies only when unavoidable)."""
+        out = []
+        for i in range(self.n_tensors):
+            t = tensors[i]
+            if t.dtype != torch.float32:
+                raise NotImplementedError(f"HIP gradient matching computes in fp32; got {t.dtype}.")
+            if t.numel() != self.numels[i]:
+                raise ValueError(
+                    f"Gradient {i} has {t.numel()} elements but the observed gradient has {self.numels[i]}."
+                )
+            if not t.is_contiguous():
+                t = t.contiguous()
+            if t.numel() and t.data_ptr() % 16:
+                t = t.clone(memory_format=torch.contiguous_format)
+            out.append(t)
+        return out
+
+    def _pointer_array(self, tensors):
+        dummy = self._dummy.data_ptr()
+        addrs = [(t.data_ptr() if t.numel() else dummy) for t in tensors]
+        for i, a in enumerate(addrs):
+            if a % 16:
+                # only reachable for the observed gradient at pack time; make an aligned copy
+                tensors[i] = tensors[i].clone(memory_format=torch.contiguous_format)
+                addrs[i] = tensors[i].data_ptr()
+        self._keepalive = tensors
+        return (c_void_p * len(addrs))(*addrs)
+
+    def matches(self, gradient_data):
+        n = min(len(gradient_data), self.n_tensors)
+        return len(gradient_data) >= self.n_tensors and tuple(t.data_ptr() for t in gradient_data[: min(4, n)]) == self._data_ptr_key
+
+    # -- launches --------------------------------------------------------------------------------------------------
+    def forward(self, kind, rec, scale, tag_scale=0.0, fudge=1e-7, weights=None):
+        """Enqueue forward + finalize; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS]."""
+        lib = _lib.load()
+        stats = torch.empty(_lib.BH_GM_STAT_WORDS, dtype=torch.float32, device=self.device)
+        stream = _lib.current_stream_handle(self.device)
+        ptrs = self._pointer_array(rec)
+        pair = self._timed("fwd")
+        if pair:
+            pair[0].record()
+        _lib.check(
+            lib.bh_gm_fwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
+                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(self.partials), stream),
+            "bh_gm_fwd",
+        )
+        if pair:
+            pair[1].record()
+        _lib.check(
+            lib.bh_gm_finalize(kind, _lib.ptr(self.partials), self.n_chunks, float(scale), float(tag_scale), float(fudge),
+                               _lib.ptr(stats), stream),
+            "bh_gm_finalize",
+        )
+        return stats
+
+    def backward(self, kind, rec, stats, gout, weights=None):
+        """Enqueue the backward launch; returns the flat gradient buffer (views are cut by the caller)."""
+        lib = _lib.load()
+        grad_flat = torch.empty(max(self.flat_elems, 4), dtype=torch.float32, device=self.device)
+        stream = _lib.current_stream_handle(self.device)
+        ptrs = self._pointer_array(rec)
+        pair = self._timed("bwd")
+        if pair:
+            pair[0].record()
+        _lib.check(
+            lib.bh_gm_bwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
+                          self._group_bounds, _lib.ptr(weights), _lib.ptr(stats), _lib.ptr(gout), _lib.ptr(grad_flat), stream),
+            "bh_gm_bwd",
+        )
+        if pair:
+            pair[1].record()
+        return grad_flat
+
+    def split(self, grad_flat):
+        return [grad_flat[o : o + n].view(s) for o, n, s in zip(self.flat_offsets, self.numels, self.shapes)]
+
+
+class _GradMatchFunction(torch.autograd.Function):
+    """objective(rec_0, ..., rec_{T-1}) as one differentiable node; backward hands autograd T views of one buffer."""
+
+    @staticmethod
+    def forward(ctx, plan, kind, scale, tag_scale, fudge, weights, *rec):
+        rec = plan._prepare(rec)
+        with torch.cuda.device(plan.device):
+            stats = plan.forward(kind, rec, scale, tag_scale, fudge, weights)
+        ctx.plan, ctx.kind, ctx.weights, ctx.stats = plan, kind, weights, stats
+        ctx.n_inputs = len(rec)
+        ctx.save_for_backward(*rec)
+        return stats[0:1]  # shape (1,) like `gradient_rec[0].new_zeros(1,)` at objectives.py:91
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        plan = ctx.plan
+        rec = list(ctx.saved_tensors)
+        gout = gout.contiguous().to(torch.float32)
+        with torch.cuda.device(plan.device):
+            grad_flat = plan.backward(ctx.kind, rec, ctx.stats, gout, ctx.weights)
+        grads = plan.split(grad_flat)
+        return (None, None, None, None, None, None, *grads)
+
+
+class HipGradientLoss(torch.nn.Module):
+    """Counterpart of ``GradientLoss`` (objectives.py:9-72) whose list reduction runs in kernel A."""
+
+    kind_name = None
+
+    def __init__(self, scale=1.0, task_regularization=0.0, **kwargs):
+        super().__init__()
+        self.scale = scale
+        self.task_regularization = task_regularization
+        self._plan = None
+
+    # objectives.py:16-24
+    def initialize(self, loss_fn, cfg_impl, local_hyperparams=None):
+        self.loss_fn = loss_fn
+        self.local_hyperparams = local_hyperparams
+        self.cfg_impl = cfg_impl
+        if getattr(cfg_impl, "mixed_precision", False):
+            raise NotImplementedError("The HIP gradient-matching path is fp32 only (impl.mixed_precision must be False).")
+        self._grad_fn = self._single_step_gradient if local_hyperparams is None else self._multi_step_update
+
+    # objectives.py:26-32
+    def forward(self, model, gradient_data, candidate, labels):
+        gradient, task_loss = self._grad_fn(model, candidate, labels)
+        objective = self.gradient_based_loss(gradient, gradient_data)
+        if self.task_regularization != 0:
+            objective = objective + self.task_regularization * task_loss
+        return objective, task_loss.detach()
+
+    def _plan_for(self, gradient_rec, gradient_data):
+        n_pairs = min(len(gradient_rec), len(gradient_data))
+        plan = self._plan
+        if plan is None or plan.n_tensors != n_pairs or not plan.matches(gradient_data):
+            plan = GradientMatchPlan(gradient_data, n_pairs)
+            self._plan = plan
+        return plan
+
+    def _weights(self, plan):
+        return None
+
+    def _extra(self):
+        return 0.0, 1e-7  # tag_scale, fudge
+
+    def gradient_based_loss(self, gradient_rec, gradient_data):
+        gradient_rec = list(gradient_rec)
+        for t in gradient_rec[:1]:
+            _require_cuda(t, "reconstructed gradient")
+        plan = self._plan_for(gradient_rec, gradient_data)
+        tag_scale, fudge = self._extra()
+        kind = _lib.GM_KINDS[self.kind_name]
+        return _GradMatchFunction.apply(plan, kind, float(self.scale), tag_scale, fudge, self._weights(plan),
+                                        *gradient_rec[: plan.n_tensors])
+
+    # objectives.py:40-46
+    def _single_step_gradient(self, model, candidate, labels):
+        model.zero_grad()
+        task_loss = self.loss_fn(model(candidate), labels)
+        gradient = torch.autograd.grad(task_loss, tuple(model.parameters()), create_graph=True)
+        return gradient, task_loss
+
+    # objectives.py:48-72 (FedAvg unroll).  Plain torch ops via torch.func; fused kernels for it are a "next" row.
+    def _multi_step_update(self, model, candidate, labels):
+        from torch.func import functional_call
+
+        model.zero_grad()
+        names = [n for n, _ in model.named_parameters()]
+        server = [p for _, p in model.named_parameters()]
+        buffers = dict(model.named_buffers())
+        params = [p.clone() for p in server]
+        hp = self.local_hyperparams
+        seen = 0
+        task_loss = None
+        for i in range(hp["steps"]):
+            data = candidate[seen : seen + hp["data_per_step"]]
+            seen = (seen + hp["data_per_step"]) % candidate.shape[0]
+            step_labels = hp["labels"][i]
+            task_loss = self.loss_fn(functional_call(model, ({**dict(zip(names, params)), **buffers},), (data,)), step_labels)
+            step_grad = torch.autograd.grad(task_loss, params, create_graph=True)
+            params = [p - hp["lr"] * g for p, g in zip(params, step_grad)]
+        return [p_local - p_server for p_local, p_server in zip(params, server)], task_loss
+
+
+class HipEuclidean(HipGradientLoss):
+    kind_name = "euclidean"
+
+    def __repr__(self):
+        return f"Euclidean loss with scale={self.scale} and task reg={self.task_regularization} [HIP gfx950]"
+
+
+class HipL1Loss(HipGradientLoss):
+    kind_name = "l1"
+
+    def __repr__(self):
+        return f"L1 loss with scale={self.scale} and task reg={self.task_regularization} [HIP gfx950]"
+
+
+class HipCosineSimilarity(HipGradientLoss):
+    kind_name = "cosine-similarity"
+
+    def __repr__(self):
+        return f"Cosine Similarity with scale={self.scale} and task reg={self.task_regularization} [HIP gfx950]"
+
+
+class HipAngularSimilarity(HipGradientLoss):
+    kind_name = "angular"
+
+    def __init__(self, scale=1.0, task_regularization=0.0, fudge_factor=1e-7, **kwargs):
+        super().__init__(scale, task_regularization)
+        self.fudge_factor = 1e-7  # the reference ignores its ctor argument (objectives.py:208)
+
+    def _extra(self):
+        return 0.0, self.fudge_factor
+
+    def __repr__(self):
+        return f"Angular Similarity with scale={self.scale} and task reg={self.task_regularization} [HIP gfx950]"
+
+
+class HipMaskedCosineSimilarity(HipGradientLoss):
+    kind_name = "masked-cosine-similarity"
+
+    def __init__(self, scale=1.0, mask_value=1e-6, task_regularization=0.0, **kwargs):
+        super().__init__(scale, task_regularization)
+        self.mask_value = 1e-6  # the reference ignores its ctor argument (objectives.py:228)
+
+    def __repr__(self):
+        return (
+            f"Masked Cosine Similarity with scale={self.scale} and task reg={self.task_regularization}. "
+            f"Mask val={self.mask_value} [HIP gfx950]"
+        )
+
+
+class HipFastCosineSimilarity(HipGradientLoss):
+    kind_name = "fast-cosine-similarity"
+
+    def __repr__(self):
+        return f"Fast Cosine Similarity with scale={self.scale} and task reg={self.task_regularization} [HIP gfx950]"
+
+
+class HipEuclideanTag(HipGradientLoss):
+    """objectives.py:98-141; the per-tensor weights ride along in a small device vector."""
+
+    kind_name = "tag-euclidean"
+
+    def __init__(self, scale=1.0, task_regularization=0.0, tag_scale=0.1, scale_scheme="linear", **kwargs):
+        super().__init__(scale, task_regularization)
+        self.tag_scale = tag_scale
+        self.scale_scheme = scale_scheme
+        self._weight_cache = None
+
+    def _extra(self):
+        return float(self.tag_scale), 1e-7
+
+    def _weights(self, plan):
+        cached = self._weight_cache
+        if cached is not None and cached[0] is plan:
+            return cached[1]
+        n = plan.n_tensors
+        setup = dict(dtype=torch.float32, device=plan.device)
+        if self.scale_scheme == "linear":  # objectives.py:117-118
+            weights = torch.arange(n, 0, -1, **setup) / n
+        elif self.scale_scheme == "exp":  # :119-122
+            weights = torch.arange(n, 0, -1, **setup).softmax(dim=0)
+            weights = weights / weights[0]
+        else:  # :123-124
+            weights = torch.ones(n, **setup)
+        weights = weights.contiguous()
+        self._weight_cache = (plan, weights)
+        return weights
+
+    def __repr__(self):
+        return (
+            f"Tag loss with scale={self.scale}, weight scheme {self.scale_scheme}, L1 scale {self.tag_scale} "
+            f"and task reg={self.task_regularization} [HIP gfx950]"
+        )
+
+
+# objectives.py:496-506.  The Pearlmutter finite-difference objectives are a SURVEY section 8(f) "next" row.
+objective_lookup = {
+    "euclidean": HipEuclidean,
+    "cosine-similarity": HipCosineSimilarity,
+    "masked-cosine-similarity": HipMaskedCosineSimilarity,
+    "fast-cosine-similarity": HipFastCosineSimilarity,
+    "angular": HipAngularSimilarity,
+    "l1": HipL1Loss,
+    "tag-euclidean": HipEuclideanTag,
+}

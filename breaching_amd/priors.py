@@ -1,0 +1,234 @@
+"""Image priors on the HIP kernels (kernels C and D), behind the reference's regulariser interface.
+
+reference: breaching/attacks/auxiliaries/regularizers.py
+  * ``TotalVariation`` :103-153, ``NormRegularization`` :184-200, ``DeepInversion`` :203-230
+  * ``regularizer_lookup`` :233-239; every regulariser has ``initialize(models, shared_data, labels)`` and
+    ``forward(tensor) -> scalar``.
+The DeepInversion feature statistic is restated from its mathematical definition (the reference hook lives in an
+NVIDIA-NC licensed file, auxiliaries/deepinversion.py:84-107, and was not copied).
+"""
+
+import torch
+from torch.autograd.function import once_differentiable
+
+from . import _lib
+
+
+def _check_image(x):
+    if not x.is_cuda:
+        raise RuntimeError(f"HIP image priors need a tensor on a ROCm device, got {x.device} (no CPU fallback).")
+    if x.dtype != torch.float32:
+        raise NotImplementedError(f"HIP image priors compute in fp32; got {x.dtype}.")
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise ValueError(f"Total variation expects a [B, 3, H, W] tensor, got {tuple(x.shape)}.")
+
+
+def launch_tv_norm(x, tv_scale, inner_exp, outer_exp, eps, double_opponents, norm_scale=0.0, norm_p=2.0,
+                   grad_out=None, partials=None):
+    """Enqueue kernel C.  Returns (grad [B,3,H,W], partials fp64 [grid*2], grid)."""
+    lib = _lib.load()
+    _check_image(x)
+    x = x.contiguous()
+    B, _, H, W = x.shape
+    if grad_out is None:
+        grad_out = torch.empty_like(x)
+    if partials is None:
+        partials = torch.empty(_lib.BH_PRIOR_MAX_GRID * _lib.BH_PRIOR_PARTIAL_STRIDE, dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        grid = _lib.check(
+            lib.bh_prior_tv_norm(_lib.ptr(x), B, H, W, float(tv_scale), float(inner_exp), float(outer_exp), float(eps),
+                                 int(bool(double_opponents)), float(norm_scale), float(norm_p), _lib.ptr(grad_out),
+                                 _lib.ptr(partials), _lib.current_stream_handle(x.device)),
+            "bh_prior_tv_norm",
+        )
+    return grad_out, partials, grid
+
+
+class _TvNormFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, tv_scale, inner_exp, outer_exp, eps, double_opponents, norm_scale, norm_p):
+        grad, partials, grid = launch_tv_norm(x.detach(), tv_scale, inner_exp, outer_exp, eps, double_opponents, norm_scale, norm_p)
+        ctx.save_for_backward(grad)
+        ctx.in_shape = x.shape
+        # fixed-order fp64 combine of the per-workgroup partial values
+        value = partials[: grid * _lib.BH_PRIOR_PARTIAL_STRIDE].sum().to(torch.float32)
+        return value
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).view(ctx.in_shape), None, None, None, None, None, None, None
+
+
+class HipTotalVariation(torch.nn.Module):
+    """regularizers.py:103-153 -- anisotropic/isotropic TV by forward differences with zero extension."""
+
+    def __init__(self, setup, scale=0.1, inner_exp=1, outer_exp=1, double_opponents=False, eps=1e-8):
+        super().__init__()
+        self.setup = setup
+        self.scale = scale
+        self.inner_exp = inner_exp
+        self.outer_exp = outer_exp
+        self.eps = eps
+        self.double_opponents = double_opponents
+
+    def initialize(self, models, *args, **kwargs):
+        pass
+
+    def forward(self, tensor, *args, **kwargs):
+        return _TvNormFunction.apply(tensor, self.scale, self.inner_exp, self.outer_exp, self.eps,
+                                     self.double_opponents, 0.0, 2.0)
+
+    def fused_terms(self):
+        return dict(tv_scale=self.scale, inner_exp=self.inner_exp, outer_exp=self.outer_exp, eps=self.eps,
+                    double_opponents=self.double_opponents)
+
+    def __repr__(self):
+        return (
+            f"Total Variation, scale={self.scale}. p={self.inner_exp} q={self.outer_exp}. "
+            f"{'Color TV: double oppponents' if self.double_opponents else ''} [HIP gfx950]"
+        )
+
+
+class HipNormRegularization(torch.nn.Module):
+    """regularizers.py:184-200 -- scale / p * mean(x^p)."""
+
+    def __init__(self, setup, scale=0.1, pnorm=2.0):
+        super().__init__()
+        self.setup = setup
+        self.scale = scale
+        self.pnorm = pnorm
+
+    def initialize(self, models, *args, **kwargs):
+        pass
+
+    def forward(self, tensor, *args, **kwargs):
+        return _TvNormFunction.apply(tensor, 0.0, 1.0, 1.0, 1e-8, False, self.scale, self.pnorm)
+
+    def fused_terms(self):
+        return dict(norm_scale=self.scale, norm_p=self.pnorm)
+
+    def __repr__(self):
+        return f"Input L^p norm regularization, scale={self.scale}, p={self.pnorm} [HIP gfx950]"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# DeepInversion
+# ---------------------------------------------------------------------------------------------------------------
+
+
+class _BnStatFunction(torch.autograd.Function):
+    """r(x) = ||running_var - var_c(x)||_2 + ||running_mean - mean_c(x)||_2 for one BN input x[B,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, running_mean, running_var):
+        lib = _lib.load()
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("HIP DeepInversion prior needs fp32 activations on a ROCm device (no CPU fallback).")
+        xc = x.detach().contiguous()
+        if xc.data_ptr() % 16:
+            xc = xc.clone()
+        B, C = xc.shape[0], xc.shape[1]
+        HW = xc.numel() // (B * C)
+        dev = xc.device
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream_handle(dev)
+            S = lib.bh_bnstat_slabs(B, C, HW)
+            sums = torch.empty(C * S * 2, dtype=torch.float64, device=dev)
+            scratch = torch.empty(2 * C, dtype=torch.float64, device=dev)
+            out = torch.empty(1 + 2 * C, dtype=torch.float32, device=dev)  # [value | coef(2C)]
+            _lib.check(lib.bh_bnstat_sums(_lib.ptr(xc), B, C, HW, _lib.ptr(sums), stream), "bh_bnstat_sums")
+            rm = running_mean.detach().to(torch.float32).contiguous()
+            rv = running_var.detach().to(torch.float32).contiguous()
+            _lib.check(
+                lib.bh_bnstat_finalize(_lib.ptr(sums), B, C, HW, _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(out),
+                                       ctypes_offset(out, 1), _lib.ptr(scratch), stream),
+                "bh_bnstat_finalize",
+            )
+        ctx.save_for_backward(xc, out)
+        ctx.dims = (B, C, HW)
+        ctx.in_shape = x.shape
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        lib = _lib.load()
+        xc, out = ctx.saved_tensors
+        B, C, HW = ctx.dims
+        grad = torch.empty_like(xc)
+        gout = gout.contiguous().to(torch.float32)
+        with torch.cuda.device(xc.device):
+            _lib.check(
+                lib.bh_bnstat_bwd(_lib.ptr(xc), B, C, HW, ctypes_offset(out, 1), _lib.ptr(gout), _lib.ptr(grad),
+                                  _lib.current_stream_handle(xc.device)),
+                "bh_bnstat_bwd",
+            )
+        return grad.view(ctx.in_shape), None, None
+
+
+def ctypes_offset(tensor, elements):
+    from ctypes import c_void_p
+
+    return c_void_p(tensor.data_ptr() + elements * tensor.element_size())
+
+
+class _BnStatHook:
+    """Forward hook on one BatchNorm2d: keeps the feature statistic of the module's *input* (deepinversion.py:93-101)."""
+
+    def __init__(self, module):
+        self.r_feature = None
+        self.handle = module.register_forward_hook(self)
+
+    def __call__(self, module, inputs, output):
+        if module.running_mean is None or module.running_var is None:
+            raise RuntimeError("DeepInversion prior needs BatchNorm running statistics (buffers) on the attacked model.")
+        self.r_feature = _BnStatFunction.apply(inputs[0], module.running_mean, module.running_var)
+
+    def close(self):
+        self.handle.remove()
+
+
+class HipDeepInversion(torch.nn.Module):
+    """regularizers.py:203-230 -- sum over BN layers of the feature statistic, first layer times 10."""
+
+    def __init__(self, setup, scale=0.1, first_bn_multiplier=10):
+        super().__init__()
+        self.setup = setup
+        self.scale = scale
+        self.first_bn_multiplier = first_bn_multiplier
+        self.losses = []
+
+    def initialize(self, models, *args, **kwargs):
+        # The reference re-registers hooks on every trial and never removes the old ones (regularizers.py:214-220);
+        # only the newest set is ever read, so dropping the stale hooks changes no value.
+        for hooks in self.losses:
+            for hook in hooks:
+                hook.close()
+        self.losses = [list() for _ in models]
+        for idx, model in enumerate(models):
+            for module in model.modules():
+                if isinstance(module, torch.nn.BatchNorm2d):
+                    self.losses[idx].append(_BnStatHook(module))
+
+    def forward(self, tensor, *args, **kwargs):
+        feature_reg = 0
+        for hooks in self.losses:
+            for idx, hook in enumerate(hooks):
+                feature_reg = feature_reg + hook.r_feature * (self.first_bn_multiplier if idx == 0 else 1.0)
+        return self.scale * feature_reg
+
+    def __repr__(self):
+        return (
+            f"Deep Inversion Regularization (matching batch norms), scale={self.scale}, "
+            f"first-bn-mult={self.first_bn_multiplier} [HIP gfx950]"
+        )
+
+
+# regularizers.py:233-239.  `orthogonality` and `features` are SURVEY section 8(f) "next" rows.
+regularizer_lookup = dict(
+    total_variation=HipTotalVariation,
+    norm=HipNormRegularization,
+    deep_inversion=HipDeepInversion,
+)

@@ -1,0 +1,315 @@
+"""GPU parity of every HIP kernel against (a) the fp64 C oracle and (b) golden vectors from the real reference.
+
+All calls go through the C ABI (ctypes) exactly like the product path.  Tolerances (fp32 arithmetic):
+  * objective values: 2e-6 relative (north_star allows 1e-4 on the final loss),
+  * gradients: 1e-5 relative to the largest magnitude of the tensor list.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+VALUE_RTOL = 2e-6
+GRAD_RTOL = 1e-5
+
+LIST_SHAPES = [(3, 5, 7), (1,), (4097,), (64, 3, 3, 3), (8192,), (130,), (2, 4100), (7,)]
+KIND_KW = {
+    "cosine-similarity": dict(scale=1.0),
+    "masked-cosine-similarity": dict(scale=0.7),
+    "fast-cosine-similarity": dict(scale=1.3),
+    "angular": dict(scale=2.0),
+    "euclidean": dict(scale=1e-2),
+    "l1": dict(scale=0.5),
+    "tag-euclidean": dict(scale=1.5, tag_scale=0.1, scale_scheme="linear"),
+    "tag-euclidean/exp": dict(scale=1.0, tag_scale=0.25, scale_scheme="exp"),
+}
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _run_hip_objective(name, kw, rec_np, data_np):
+    from breaching_amd.gm import objective_lookup
+
+    obj = objective_lookup[name.split("/")[0]](**kw)
+    rec = [torch.tensor(r, device=_dev(), requires_grad=True) for r in rec_np]
+    data = [torch.tensor(d, device=_dev()) for d in data_np]
+    value = obj.gradient_based_loss(rec, data)
+    grads = torch.autograd.grad(value.sum(), rec)
+    return value.detach().cpu().numpy().reshape(-1), [g.cpu().numpy() for g in grads]
+
+
+def _assert_grads(got, want, rtol=GRAD_RTOL):
+    peak = max(float(np.abs(w).max()) for w in want) or 1.0
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape
+        err = float(np.abs(g.astype(np.float64) - w).max())
+        assert err <= rtol * peak, f"tensor {i}: max abs err {err} vs peak {peak}"
+
+
+@pytest.mark.parametrize("name", list(KIND_KW))
+def test_gm_matches_reference_golden(name, golden_dir, hip_lib):
+    gold = np.load(os.path.join(golden_dir, "kernels.npz"))
+    rec_np = [gold[f"rec_{i}"] for i in range(len(LIST_SHAPES))]
+    data_np = [gold[f"data_{i}"] for i in range(len(LIST_SHAPES))]
+    value, grads = _run_hip_objective(name, KIND_KW[name], rec_np, data_np)
+    key = name.replace("/", "_")
+    want = float(gold[f"{key}__value"][0])
+    assert abs(value[0] - want) <= 5e-6 * abs(want) + 1e-7  # the reference itself sums in fp32
+    _assert_grads(grads, [gold[f"{key}__grad_{i}"].astype(np.float64) for i in range(len(LIST_SHAPES))], rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", list(KIND_KW))
+def test_gm_matches_c_oracle(name, kernels_oracle, hip_lib):
+    from oracle import kernels_ref
+
+    rng = np.random.default_rng(7)
+    shapes = [(5000,), (3,), (4096,), (4095,), (12289,), (1, 1), (33, 65)]
+    rec_np = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    data_np = [(r * 0.8 + rng.standard_normal(s).astype(np.float32) * 0.2) for r, s in zip(rec_np, shapes)]
+    data_np[0][:100] = 0.0
+    kw = dict(KIND_KW[name])
+    kind = name.split("/")[0]
+    weights = kernels_ref.tag_weights(len(shapes), kw.get("scale_scheme", "linear")) if kind == "tag-euclidean" else None
+    want_v, want_g = kernels_ref.gm(kind, rec_np, data_np, scale=kw["scale"], tag_scale=kw.get("tag_scale", 0.0), weights=weights)
+    value, grads = _run_hip_objective(name, kw, rec_np, data_np)
+    assert abs(value[0] - want_v) <= VALUE_RTOL * abs(want_v) + 1e-9
+    _assert_grads(grads, want_g)
+
+
+def test_gm_zip_truncation_and_upstream_gradient(kernels_oracle, hip_lib):
+    """Shorter observed list drops trailing pairs (objectives.py:190 zip); upstream gradient scales the result."""
+    from breaching_amd.gm import HipEuclidean
+    from oracle import kernels_ref
+
+    rng = np.random.default_rng(3)
+    rec_np = [rng.standard_normal(s).astype(np.float32) for s in [(10,), (4100,), (6,)]]
+    data_np = [rng.standard_normal(s).astype(np.float32) for s in [(10,), (4100,)]]
+    rec = [torch.tensor(r, device=_dev(), requires_grad=True) for r in rec_np]
+    data = [torch.tensor(d, device=_dev()) for d in data_np]
+    value = HipEuclidean(scale=0.5).gradient_based_loss(rec, data)
+    grads = torch.autograd.grad((value * 3.0).sum(), rec, allow_unused=True)
+    want_v, want_g = kernels_ref.gm("euclidean", rec_np[:2], data_np, scale=0.5)
+    assert abs(value.item() - want_v) <= VALUE_RTOL * abs(want_v)
+    assert grads[2] is None
+    _assert_grads([g.cpu().numpy() for g in grads[:2]], [3.0 * g for g in want_g])
+
+
+def test_gm_full_size_properties(hip_lib):
+    """ResNet-18 sized list (N = 11.69 M): size-independent properties at BASELINE size.
+
+    cosine(r, r) = 0 and its gradient vanishes; cosine(r, -r) = 2; cosine is scale invariant; euclid(r, d) matches a
+    torch fp64 evaluation; gradient of euclid is r - d."""
+    from breaching_amd.cases import ResNet
+    from breaching_amd.gm import HipCosineSimilarity, HipEuclidean
+
+    torch.manual_seed(0)
+    shapes = [tuple(p.shape) for p in ResNet(18, 1000).parameters()]
+    assert sum(int(np.prod(s)) for s in shapes) == 11_689_512 and len(shapes) == 62
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    r_list = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
+    d_list = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
+
+    def cos(rec, data):
+        rec = [t.clone().requires_grad_(True) for t in rec]
+        v = HipCosineSimilarity().gradient_based_loss(rec, data)
+        g = torch.autograd.grad(v.sum(), rec)
+        return v.item(), g
+
+    v_same, g_same = cos(r_list, r_list)
+    assert abs(v_same) < 1e-6
+    assert max(float(g.abs().max()) for g in g_same) < 1e-9
+    v_neg, _ = cos(r_list, [-t for t in r_list])
+    assert abs(v_neg - 2.0) < 1e-6
+    v1, g1 = cos(r_list, d_list)
+    v2, g2 = cos([2.5 * t for t in r_list], [0.125 * t for t in d_list])
+    assert abs(v1 - v2) < 2e-6
+    ref = 1 - sum((r.double() * d.double()).sum() for r, d in zip(r_list, d_list)) / (
+        torch.sqrt(sum((r.double() ** 2).sum() for r in r_list)) * torch.sqrt(sum((d.double() ** 2).sum() for d in d_list)))
+    assert abs(v1 - ref.item()) <= 2e-6 * abs(ref.item())
+    for a, b in zip(g1, g2):  # d/dr of a scale-invariant function scales inversely
+        torch.testing.assert_close(a, 2.5 * b, rtol=2e-5, atol=1e-9)
+
+    rec = [t.clone().requires_grad_(True) for t in r_list]
+    v = HipEuclidean().gradient_based_loss(rec, d_list)
+    g = torch.autograd.grad(v.sum(), rec)
+    want = 0.5 * sum(((r.double() - d.double()) ** 2).sum() for r, d in zip(r_list, d_list))
+    assert abs(v.item() - want.item()) <= VALUE_RTOL * want.item()
+    for gi, r, d in zip(g, r_list, d_list):
+        torch.testing.assert_close(gi, r - d, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("key,kw", [
+    ("p1q1", dict(scale=0.2, inner_exp=1, outer_exp=1, double_opponents=False)),
+    ("p1q1_opp", dict(scale=0.3, inner_exp=1, outer_exp=1, double_opponents=True)),
+    ("p2q05_opp", dict(scale=0.1, inner_exp=2, outer_exp=0.5, double_opponents=True)),
+    ("p2q05", dict(scale=1e-4, inner_exp=2, outer_exp=0.5, double_opponents=False)),
+])
+def test_total_variation_matches_reference_golden(key, kw, golden_dir, hip_lib):
+    from breaching_amd.priors import HipTotalVariation
+
+    gold = np.load(os.path.join(golden_dir, "kernels.npz"))
+    x = torch.tensor(gold["tv_x"], device=_dev(), requires_grad=True)
+    value = HipTotalVariation(dict(device=_dev(), dtype=torch.float32), **kw)(x)
+    (g,) = torch.autograd.grad(value, x)
+    want = float(gold[f"tv_{key}__value"][0])
+    assert abs(value.item() - want) <= 5e-6 * abs(want)
+    _assert_grads([g.cpu().numpy()], [gold[f"tv_{key}__grad"].astype(np.float64)], rtol=5e-5 if "p2" in key else 1e-6)
+
+
+@pytest.mark.parametrize("key,kw", [("p2", dict(scale=1e-2, pnorm=2)), ("p3", dict(scale=0.3, pnorm=3.0))])
+def test_norm_prior_matches_reference_golden(key, kw, golden_dir, hip_lib):
+    from breaching_amd.priors import HipNormRegularization
+
+    gold = np.load(os.path.join(golden_dir, "kernels.npz"))
+    x = torch.tensor(gold["tv_x"], device=_dev(), requires_grad=True)
+    value = HipNormRegularization(dict(device=_dev(), dtype=torch.float32), **kw)(x)
+    (g,) = torch.autograd.grad(value, x)
+    want = float(gold[f"norm_{key}__value"][0])
+    assert abs(value.item() - want) <= 5e-6 * abs(want)
+    _assert_grads([g.cpu().numpy()], [gold[f"norm_{key}__grad"].astype(np.float64)], rtol=1e-5)
+
+
+@pytest.mark.parametrize("shape,opp", [((1, 3, 224, 224), False), ((8, 3, 224, 224), False), ((2, 3, 33, 17), True), ((1, 3, 1, 1), False)])
+def test_tv_norm_matches_c_oracle(shape, opp, kernels_oracle, hip_lib):
+    from breaching_amd.priors import launch_tv_norm
+    from oracle import kernels_ref
+
+    rng = np.random.default_rng(11)
+    x_np = rng.standard_normal(shape).astype(np.float32)
+    x = torch.tensor(x_np, device=_dev())
+    grad, partials, grid = launch_tv_norm(x, 0.2, 1, 1, 1e-8, opp, norm_scale=1e-3, norm_p=2.0)
+    vals = partials[: grid * 2].view(grid, 2).sum(dim=0).cpu().numpy()
+    tv, nrm, want_g = kernels_ref.tv_norm(x_np, 0.2, 1, 1, 1e-8, opp, 1e-3, 2.0)
+    assert abs(vals[0] - tv) <= 1e-6 * abs(tv) + 1e-12
+    assert abs(vals[1] - nrm) <= 1e-6 * abs(nrm) + 1e-12
+    _assert_grads([grad.cpu().numpy()], [want_g], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib):
+    from breaching_amd.priors import _BnStatFunction
+
+    gold = np.load(os.path.join(golden_dir, "kernels.npz"))
+    x = torch.tensor(gold[f"bn_{tag}__x"], device=_dev(), requires_grad=True)
+    rm = torch.tensor(gold[f"bn_{tag}__rm"], device=_dev())
+    rv = torch.tensor(gold[f"bn_{tag}__rv"], device=_dev())
+    value = _BnStatFunction.apply(x, rm, rv)
+    (g,) = torch.autograd.grad(value, x)
+    want = float(gold[f"bn_{tag}__value"][0])
+    assert abs(value.item() - want) <= 5e-6 * abs(want)
+    _assert_grads([g.cpu().numpy()], [gold[f"bn_{tag}__grad"].astype(np.float64)], rtol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(8, 64, 112, 112), (8, 2048, 7, 7), (2, 256, 14, 14), (1, 3, 5, 5)])
+def test_bnstat_matches_c_oracle(shape, kernels_oracle, hip_lib):
+    from breaching_amd.priors import _BnStatFunction
+    from oracle import kernels_ref
+
+    rng = np.random.default_rng(13)
+    if np.prod(shape) > 2_000_000:  # keep the scalar C oracle within seconds: full size for the HIP side, checked by sampling
+        B, C = shape[0], shape[1]
+        x_np = rng.standard_normal(shape).astype(np.float32) * 2 + 0.5
+    else:
+        x_np = rng.standard_normal(shape).astype(np.float32) * 2 + 0.5
+    C = shape[1]
+    rm = rng.standard_normal(C).astype(np.float32) * 0.1
+    rv = (rng.random(C).astype(np.float32) + 0.5)
+    x = torch.tensor(x_np, device=_dev(), requires_grad=True)
+    value = _BnStatFunction.apply(x, torch.tensor(rm, device=_dev()), torch.tensor(rv, device=_dev()))
+    (g,) = torch.autograd.grad(value * 1.5, x)
+    want_v, want_g, _, _ = kernels_ref.bnstat(x_np, rm, rv)
+    assert abs(value.item() - want_v) <= 2e-6 * abs(want_v)
+    _assert_grads([g.cpu().numpy()], [1.5 * want_g], rtol=1e-5)
+
+
+def _step_once(hip_lib, n_shape, sign_mode, boxed, decoupled, langevin, clip, steps=3, soft_max_it=50):
+    """Drive bh_loss_commit + bh_grad_norm + bh_candidate_step for a few iterations; compare with the C oracle."""
+    from breaching_amd import _lib, schedules
+    from oracle import kernels_ref
+
+    dev = _dev()
+    rng = np.random.default_rng(17)
+    B, C, H, W = n_shape
+    n = B * C * H * W
+    x_np = rng.standard_normal(n).astype(np.float32)
+    lo, hi = [-2.0, -1.9, -1.8], [2.2, 2.3, 2.4]
+    hp = dict(betas=(0.9, 0.999), eps=1e-8, wd=0.01 if decoupled else 0.0)
+    lrs = schedules.lr_sequence(0.1, "cosine-decay", 2, soft_max_it)
+    table = schedules.adam_schedule_table(lrs, hp["betas"][0], hp["betas"][1], hp["wd"])
+    sched = torch.from_numpy(table).to(dev)
+    state = torch.zeros(_lib.BH_STATE_WORDS, dtype=torch.int32, device=dev)
+    history = torch.zeros(soft_max_it, dtype=torch.float32, device=dev)
+    ws = torch.empty(_lib.BH_PRIOR_MAX_GRID, dtype=torch.float64, device=dev)
+    x = torch.tensor(x_np, device=dev)
+    m, v, best = torch.zeros_like(x), torch.zeros_like(x), x.clone()
+    P = _lib.StepParams()
+    P.n, P.plane, P.channels, P.boxed, P.sign_mode, P.max_iterations = n, H * W, C, int(boxed), sign_mode, soft_max_it
+    for c in range(3):
+        P.lo[c], P.hi[c] = lo[c], hi[c]
+    P.beta1, P.beta2, P.eps, P.decoupled_wd, P.langevin, P.grad_clip = 0.9, 0.999, 1e-8, int(decoupled), langevin, clip
+    stream = _lib.current_stream_handle(dev)
+    _lib.check(hip_lib.bh_state_reset(_lib.ptr(state), stream), "reset")
+    xo, mo, vo = x_np.astype(np.float64), np.zeros(n), np.zeros(n)
+    losses = [3.0, 2.0, 2.5, 1.0, float("nan"), 0.5]
+    best_o = xo.copy()
+    min_o, dead = float("inf"), False
+    for it in range(steps):
+        g_np = rng.standard_normal(n).astype(np.float32) * (10.0 if clip > 0 else 1.0)
+        greg_np = rng.standard_normal(n).astype(np.float32) * 0.1
+        noise_np = rng.standard_normal(n).astype(np.float32) if langevin > 0 else None
+        g, greg = torch.tensor(g_np, device=dev), torch.tensor(greg_np, device=dev)
+        noise = torch.tensor(noise_np, device=dev) if noise_np is not None else None
+        loss = torch.tensor([losses[it]], dtype=torch.float32, device=dev)
+        _lib.check(hip_lib.bh_loss_commit(_lib.ptr(state), _lib.ptr(history), soft_max_it, _lib.ptr(loss), None, 0, None, None, stream), "commit")
+        if clip > 0:
+            _lib.check(hip_lib.bh_grad_norm(_lib.ptr(state), _lib.ptr(g), _lib.ptr(greg), _lib.ptr(noise), n, _lib.ptr(sched), langevin, _lib.ptr(ws), stream), "norm")
+        _lib.check(hip_lib.bh_candidate_step(_lib.ptr(state), _lib.ptr(sched), P, _lib.ptr(x), _lib.ptr(g), _lib.ptr(greg), _lib.ptr(noise),
+                                             _lib.ptr(m), _lib.ptr(v), _lib.ptr(best), stream), "step")
+        # oracle: fp32-rounded gradient sum like the kernel input, everything else fp64
+        g_eff = (g_np + greg_np).astype(np.float64)
+        xo, mo, vo = kernels_ref.candidate_step(xo, g_eff, mo, vo, lrs[it], it + 1, 0.9, 0.999, 1e-8, hp["wd"], decoupled, sign_mode, it,
+                                                soft_max_it, noise_np, langevin, clip, boxed, lo + [0.0], hi + [0.0], H * W, C)
+        improved = (not dead) and (losses[it] < min_o)
+        if improved:
+            min_o, best_o = losses[it], xo.copy()
+        if not dead and not np.isfinite(losses[it]):
+            dead = True
+    torch.cuda.synchronize()
+    return dict(x=x.cpu().numpy(), m=m.cpu().numpy(), v=v.cpu().numpy(), best=best.cpu().numpy(), state=state.cpu(),
+                history=history.cpu().numpy(), xo=xo, mo=mo, vo=vo, best_o=best_o, min_o=min_o, losses=losses)
+
+
+@pytest.mark.parametrize("sign_mode,boxed,decoupled,langevin,clip", [
+    (1, True, False, 0.0, 0.0),   # invertinggradients: hard sign, boxed Adam
+    (0, True, False, 0.01, 0.0),  # see-through: Langevin noise
+    (0, False, True, 0.0, 1.0),   # TAG: AdamW + clipping
+    (2, True, False, 0.0, 0.0),   # modern: soft sign
+])
+def test_candidate_step_matches_c_oracle(sign_mode, boxed, decoupled, langevin, clip, kernels_oracle, hip_lib):
+    r = _step_once(hip_lib, (2, 3, 9, 7), sign_mode, boxed, decoupled, langevin, clip, steps=6)
+    np.testing.assert_allclose(r["x"], r["xo"], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(r["m"], r["mo"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(r["v"], r["vo"], rtol=2e-5, atol=1e-7)
+    # best tracking semantics (optimization_based_attack.py:119-121, :131-135)
+    from breaching_amd import _lib
+
+    st = r["state"]
+    assert st[_lib.STATE_IT].item() == 5
+    assert st[_lib.STATE_DEAD].item() == 1 and st[_lib.STATE_FIRST_BAD].item() == 4
+    assert st[_lib.STATE_MIN : _lib.STATE_MIN + 1].view(torch.float32).item() == 1.0  # 0.5 after the NaN is ignored
+    np.testing.assert_array_equal(r["history"][:4], np.float32(r["losses"][:4]))
+
+
+def test_candidate_step_best_copy_is_post_step_candidate(kernels_oracle, hip_lib):
+    r = _step_once(hip_lib, (1, 3, 8, 8), 1, True, False, 0.0, 0.0, steps=4)
+    # losses 3, 2, 2.5, 1 -> improvements at iterations 0, 1, 3 -> best == candidate after the 4th step
+    np.testing.assert_array_equal(r["best"], r["x"])
+    r = _step_once(hip_lib, (1, 3, 8, 8), 1, True, False, 0.0, 0.0, steps=3)
+    assert not np.array_equal(r["best"], r["x"])  # iteration 2 (loss 2.5) did not improve
+    np.testing.assert_allclose(r["best"], r["best_o"], rtol=2e-5, atol=2e-6)

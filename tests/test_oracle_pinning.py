@@ -1,0 +1,221 @@
+"""Pin the oracles (CPU, no GPU needed) against golden vectors produced by the unmodified reference.
+
+tests/golden/*.npz come from oracle/make_golden.py, which runs the real reference through oracle/ref_shim.py in the
+build container.  An oracle that passes here may be used as the checker for the HIP path on the GPU box.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+LIST_N = 8
+KIND_KW = {
+    "cosine-similarity": dict(scale=1.0),
+    "masked-cosine-similarity": dict(scale=0.7),
+    "fast-cosine-similarity": dict(scale=1.3),
+    "angular": dict(scale=2.0),
+    "euclidean": dict(scale=1e-2),
+    "l1": dict(scale=0.5),
+    "tag-euclidean": dict(scale=1.5, tag_scale=0.1, scale_scheme="linear"),
+    "tag-euclidean/exp": dict(scale=1.0, tag_scale=0.25, scale_scheme="exp"),
+}
+
+
+def _gold(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _peak(arrs):
+    return max(float(np.abs(a).max()) for a in arrs) or 1.0
+
+
+# ---- C kernel oracle -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(KIND_KW))
+def test_c_oracle_gradient_matching(name, golden_dir, kernels_oracle):
+    from oracle import kernels_ref
+
+    gold = _gold(golden_dir, "kernels.npz")
+    rec = [gold[f"rec_{i}"] for i in range(LIST_N)]
+    data = [gold[f"data_{i}"] for i in range(LIST_N)]
+    kw = KIND_KW[name]
+    kind = name.split("/")[0]
+    weights = kernels_ref.tag_weights(LIST_N, kw["scale_scheme"]) if kind == "tag-euclidean" else None
+    value, grads = kernels_ref.gm(kind, rec, data, scale=kw["scale"], tag_scale=kw.get("tag_scale", 0.0), weights=weights)
+    key = name.replace("/", "_")
+    want = float(gold[f"{key}__value"][0])
+    assert abs(value - want) <= 5e-6 * abs(want) + 1e-7  # the reference accumulates in fp32
+    want_g = [gold[f"{key}__grad_{i}"] for i in range(LIST_N)]
+    peak = _peak(want_g)
+    for g, w in zip(grads, want_g):
+        assert float(np.abs(g - w).max()) <= 2e-5 * peak
+
+
+@pytest.mark.parametrize("key,kw", [
+    ("p1q1", dict(tv_scale=0.2, inner_exp=1, outer_exp=1, double_opponents=False)),
+    ("p1q1_opp", dict(tv_scale=0.3, inner_exp=1, outer_exp=1, double_opponents=True)),
+    ("p2q05_opp", dict(tv_scale=0.1, inner_exp=2, outer_exp=0.5, double_opponents=True)),
+    ("p2q05", dict(tv_scale=1e-4, inner_exp=2, outer_exp=0.5, double_opponents=False)),
+])
+def test_c_oracle_total_variation(key, kw, golden_dir, kernels_oracle):
+    from oracle import kernels_ref
+
+    gold = _gold(golden_dir, "kernels.npz")
+    tv, _, grad = kernels_ref.tv_norm(gold["tv_x"], **kw)
+    want = float(gold[f"tv_{key}__value"][0])
+    assert abs(tv - want) <= 5e-6 * abs(want)
+    want_g = gold[f"tv_{key}__grad"]
+    assert float(np.abs(grad - want_g).max()) <= 5e-5 * _peak([want_g])
+
+
+@pytest.mark.parametrize("key,kw", [("p2", dict(norm_scale=1e-2, norm_p=2)), ("p3", dict(norm_scale=0.3, norm_p=3.0))])
+def test_c_oracle_norm_prior(key, kw, golden_dir, kernels_oracle):
+    from oracle import kernels_ref
+
+    gold = _gold(golden_dir, "kernels.npz")
+    _, nrm, grad = kernels_ref.tv_norm(gold["tv_x"], tv_scale=0.0, **kw)
+    want = float(gold[f"norm_{key}__value"][0])
+    assert abs(nrm - want) <= 5e-6 * abs(want)
+    assert float(np.abs(grad - gold[f"norm_{key}__grad"]).max()) <= 1e-5 * _peak([gold[f"norm_{key}__grad"]])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_c_oracle_bn_statistic(tag, golden_dir, kernels_oracle):
+    from oracle import kernels_ref
+
+    gold = _gold(golden_dir, "kernels.npz")
+    value, grad, _, _ = kernels_ref.bnstat(gold[f"bn_{tag}__x"], gold[f"bn_{tag}__rm"], gold[f"bn_{tag}__rv"])
+    want = float(gold[f"bn_{tag}__value"][0])
+    assert abs(value - want) <= 5e-6 * abs(want)
+    assert float(np.abs(grad - gold[f"bn_{tag}__grad"]).max()) <= 2e-5 * _peak([gold[f"bn_{tag}__grad"]])
+
+
+def test_c_oracle_candidate_step_against_torch_adam(kernels_oracle):
+    """The Adam part is torch.optim (third-party arithmetic); the step oracle must track it to fp32 rounding."""
+    from oracle import kernels_ref
+
+    rng = np.random.default_rng(0)
+    for decoupled, wd, eps, name in [(False, 0.0, 1e-8, "adam"), (True, 0.01, 1e-6, "adamw")]:
+        x0 = rng.standard_normal(500).astype(np.float32)
+        p = torch.tensor(x0, requires_grad=True)
+        opt = (torch.optim.AdamW([p], lr=0.05, eps=eps, weight_decay=wd) if decoupled else torch.optim.Adam([p], lr=0.05, eps=eps))
+        x, m, v = x0.astype(np.float64), np.zeros(500), np.zeros(500)
+        for step in range(1, 6):
+            g = rng.standard_normal(500).astype(np.float32)
+            p.grad = torch.tensor(g)
+            opt.step()
+            x, m, v = kernels_ref.candidate_step(x, g, m, v, 0.05, step, eps=eps, weight_decay=wd, decoupled=decoupled)
+        np.testing.assert_allclose(p.detach().numpy(), x, rtol=1e-5, atol=1e-6)
+
+
+# ---- loop-level restatement --------------------------------------------------------------------------------------
+def _cpu_case(model, data, n, **kw):
+    from breaching_amd.cases import build_case
+
+    return build_case(model, data, n, device="cpu", **kw)
+
+
+def _run_restatement(case, cfg, x0, dryrun=False, seed=7):
+    from oracle import restate
+
+    torch.manual_seed(seed)
+    return restate.run_attack(case.model, case.loss_fn, cfg, case.server_payload, case.shared_data, initial_data=x0, dryrun=dryrun)
+
+
+def _compare(prefix, gold, rec, stats, case, crop=None, exact=True):
+    from breaching_amd.cases import parameter_checksum, psnr
+
+    assert parameter_checksum(case.model) == pytest.approx(float(gold[f"{prefix}model_checksum"]), rel=1e-12)
+    hist = np.asarray(stats["Trial_0_Val"])
+    np.testing.assert_allclose(hist, gold[f"{prefix}history"], rtol=1e-5 if exact else 1e-4)
+    assert stats["opt_value"] == pytest.approx(float(gold[f"{prefix}opt_value"]), rel=1e-5 if exact else 1e-4)
+    assert abs(psnr(rec["data"], case.true_user_data["data"], case.data_cfg) - float(gold[f"{prefix}psnr"])) <= 0.01
+    data = rec["data"].numpy()
+    if crop is not None:
+        data = data[..., :crop, :crop]
+    assert np.isclose(data, gold[f"{prefix}rec"], rtol=1e-4, atol=1e-4).mean() > 0.999
+
+
+def test_restatement_convnet_invertinggradients(golden_dir):
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import initial_candidate
+
+    torch.set_num_threads(8)
+    gold = _gold(golden_dir, "attack_convnet.npz")
+    case = _cpu_case("convnet", "CIFAR10", 1)
+    x0 = initial_candidate(case.data_cfg, 1)
+    rec, stats = _run_restatement(case, get_attack_config("invertinggradients", ["optim.max_iterations=100", "optim.callback=50"]), x0)
+    _compare("", gold, rec, stats, case)
+    rec, stats = _run_restatement(case, get_attack_config("invertinggradients", ["optim.max_iterations=100"]), x0, dryrun=True)
+    assert len(stats["Trial_0_Val"]) == 1
+    _compare("dryrun_", gold, rec, stats, case)
+
+
+def test_restatement_convnet_euclidean_softsign(golden_dir):
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import initial_candidate
+
+    torch.set_num_threads(8)
+    gold = _gold(golden_dir, "attack_convnet.npz")
+    case = _cpu_case("convnet", "CIFAR10", 1)
+    x0 = initial_candidate(case.data_cfg, 1)
+    cfg = get_attack_config("invertinggradients", [
+        "objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft", "optim.step_size_decay=cosine-decay",
+        "optim.warmup=5", "optim.max_iterations=40", "restarts.scoring=euclidean", "regularization.norm.scale=0.01",
+        "regularization.norm.pnorm=2", "optim.callback=20"])
+    rec, stats = _run_restatement(case, cfg, x0)
+    _compare("l2soft_", gold, rec, stats, case)
+
+
+def test_restatement_resnet18_imagenet(golden_dir):
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import initial_candidate
+
+    torch.set_num_threads(8)
+    gold = _gold(golden_dir, "attack_resnet18.npz")
+    case = _cpu_case("resnet18", "ImageNet", 1)
+    x0 = initial_candidate(case.data_cfg, 1)
+    cfg = get_attack_config("invertinggradients", ["optim.max_iterations=20", "optim.step_size_decay=null", "optim.callback=5"])
+    rec, stats = _run_restatement(case, cfg, x0)
+    _compare("", gold, rec, stats, case, crop=32)
+
+
+def test_restatement_resnet50_seethrough_with_langevin_noise(golden_dir):
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import initial_candidate
+
+    torch.set_num_threads(8)
+    gold = _gold(golden_dir, "attack_seethrough.npz")
+    case = _cpu_case("resnet50", "ImageNet", 2, provide_buffers=True)
+    x0 = initial_candidate(case.data_cfg, 2)
+    cfg = get_attack_config("seethroughgradients", ["optim.max_iterations=4", "optim.warmup=2", "optim.callback=2"])
+    rec, stats = _run_restatement(case, cfg, x0, seed=11)
+    _compare("noise_", gold, rec, stats, case, crop=32, exact=False)
+
+
+# ---- host logic pinned to the reference -------------------------------------------------------------------------
+def test_schedules_match_reference(golden_dir):
+    from breaching_amd.schedules import lr_sequence
+
+    gold = _gold(golden_dir, "schedules.npz")
+    for key in gold.files:
+        sched, warm, max_it, step = key.split("_")
+        sched = None if sched == "none" else sched
+        mine = lr_sequence(float(step), sched, int(warm), int(max_it))
+        np.testing.assert_array_equal(np.asarray(mine), gold[key], err_msg=key)
+
+
+def test_attack_configs_match_reference_yaml(golden_dir):
+    from breaching_amd.config import get_attack_config, get_data_config
+
+    with open(os.path.join(golden_dir, "configs.json")) as f:
+        gold = json.load(f)
+    for name, want in gold["attacks"].items():
+        got = json.loads(json.dumps(get_attack_config(name)))
+        assert got == want, name
+    for name, want in gold["data"].items():
+        got = get_data_config(name)
+        for key, value in want.items():
+            assert list(got[key]) == list(value) if isinstance(value, list) else got[key] == value, (name, key)
