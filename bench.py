@@ -37,6 +37,8 @@ def parse_args():
     p.add_argument("--cpu-baseline-iters", type=int, default=6, help="timed CPU iterations of the oracle (0 disables)")
     p.add_argument("--model", default="resnet18")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in the timed region")
+    p.add_argument("--roofline-steps", type=int, default=40, help="eager iterations with per-launch HIP events")
     return p.parse_args()
 
 
@@ -82,11 +84,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    if args.no_graph:
+        run.disable_graph()
     for _ in range(args.warmup):
         run.step()
     plan = attacker.objective._plan
-    if plan is not None and not args.no_kernel_timing:
-        plan.enable_timing()
+    timed_with_events = plan is not None and not args.no_kernel_timing and run.graph is None
+    if timed_with_events:
+        plan.enable_timing()  # eager timed region: the events ride inside it
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -97,23 +102,43 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    mode = "hipGraph replay" if run.graph is not None else "eager launches"
+    graph_failed = run.graph_failed
+
+    # A replayed graph cannot carry host-visible event pairs, so when the timed region ran as graph replays the same
+    # iteration body is continued eagerly for a few more steps with a HIP event pair around every kernel-A launch.
+    eager_ms = None
+    if plan is not None and not args.no_kernel_timing and not timed_with_events:
+        run.disable_graph()
+        for _ in range(3):
+            run.step()
+        plan.enable_timing()
+        barrier()
+        te = time.perf_counter()
+        for _ in range(args.roofline_steps):
+            run.step()
+        barrier()
+        eager_ms = (time.perf_counter() - te) / max(args.roofline_steps, 1) * 1e3
 
     # ---- kernel timing (HIP events recorded on the launch stream during the timed region) -----------------------------
     roofline = None
     kernels = {}
     if plan is not None and plan.timers is not None:
+        measured = plan.drain_timers()
         for key, bytes_per in (("fwd", 2 * n_elements * 4), ("bwd", 3 * n_elements * 4)):
-            pairs = plan.timers[key]
-            if pairs:
-                ms = sorted(a.elapsed_time(b) for a, b in pairs)
-                avg_ms = sum(ms) / len(ms)
-                kernels[key] = dict(avg_us=avg_ms * 1e3, median_us=ms[len(ms) // 2] * 1e3, launches=len(ms),
-                                    algorithmic_bytes=bytes_per, achieved_GBs=bytes_per / (avg_ms * 1e-3) / 1e9)
+            us = sorted(measured.get(key, []))
+            if us:
+                avg_us = sum(us) / len(us)
+                kernels[key] = dict(avg_us=avg_us, median_us=us[len(us) // 2], min_us=us[0], launches=len(us),
+                                    algorithmic_bytes=bytes_per, achieved_GBs=bytes_per / (avg_us * 1e-6) / 1e9)
         if "fwd" in kernels:
             k = kernels["fwd"]
             roofline = dict(bound="hbm", kernel="gm_fwd_kernel<cosine>", achieved=round(k["achieved_GBs"], 1), peak=HBM_PEAK_GBS,
                             unit="GB/s", frac=round(k["achieved_GBs"] / HBM_PEAK_GBS, 4), traffic=None,
-                            avg_launch_us=round(k["avg_us"], 2), algorithmic_bytes=k["algorithmic_bytes"])
+                            avg_launch_us=round(k["avg_us"], 2), algorithmic_bytes=k["algorithmic_bytes"],
+                            measured="HIP event pair recorded from C around each launch, " +
+                                     ("inside the timed region" if timed_with_events else
+                                      f"{args.roofline_steps} eager iterations right after the graph-replay timed region"))
 
     # ---- trial selection: the one collective of the multi-GPU path --------------------------------------------------
     select_ms = None
@@ -166,6 +191,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,
+            "launch_mode": mode,
+            "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
+            "graph_capture_error": graph_failed,
             "final_objective": state["total"],
             "select_ms": select_ms,
         }

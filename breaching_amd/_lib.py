@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from . import build as _build
 
 # ---- constants mirrored from include/breach_hip.h (checked against the library in tests) -------------------------
-BH_ABI_VERSION = 1
+BH_ABI_VERSION = 2
 BH_GM_CHUNK = 4096
 BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
@@ -66,12 +66,14 @@ _PROTOTYPES = {
     "bh_gm_group_bounds": (c_int, [c_int32, POINTER(GmChunk), c_int64, POINTER(c_int32)]),
     "bh_gm_fwd": (
         c_int,
-        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p, c_void_p],
+        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p, c_void_p,
+         c_void_p, c_void_p],
     ),
     "bh_gm_finalize": (c_int, [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_void_p, c_void_p]),
     "bh_gm_bwd": (
         c_int,
-        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p],
     ),
     "bh_gm_pack": (c_int, [c_int32, POINTER(c_void_p), c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p]),
     "bh_prior_tv_norm": (
@@ -85,6 +87,10 @@ _PROTOTYPES = {
         [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "bh_bnstat_bwd": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bh_event_create": (c_int, [POINTER(c_void_p)]),
+    "bh_event_destroy": (c_int, [c_void_p]),
+    "bh_event_record": (c_int, [c_void_p, c_void_p]),
+    "bh_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "bh_state_reset": (c_int, [c_void_p, c_void_p]),
     "bh_loss_commit": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "bh_grad_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p]),

@@ -639,6 +639,19 @@ class HipOptimizationAttacker:
         return tuple(torch.zeros_like(s) for s in optimal_solution)
 
 
+GRAPH_WARMUP_ITERATIONS = 3
+
+
+def graph_replay_enabled(cfg):
+    """hipGraph replay is on unless BREACH_HIP_GRAPH=0 or cfg.impl.hip_graph is false."""
+    import os
+
+    if os.environ.get("BREACH_HIP_GRAPH", "1") == "0":
+        return False
+    flag = _cfg_get(cfg.impl, "hip_graph", True)
+    return bool(flag) if flag is not None else True
+
+
 class FusedTrial:
     """Device-resident state of one trial of the fused loop plus ``step()``, the body of one attack iteration.
 
@@ -706,8 +719,41 @@ class FusedTrial:
         with torch.cuda.device(device):
             _lib.check(lib.bh_state_reset(_lib.ptr(self.state), _lib.current_stream_handle(device)), "bh_state_reset")
         self.iterations = 0
+        # hipGraph replay of the whole iteration: the loop is launch-bound (~1.2k kernels per ResNet-18 iteration), and
+        # nothing in step() needs the host, so after a few eager iterations the body is captured once and replayed.
+        self.graph = None
+        self.graph_failed = None
+        self.capture_after = GRAPH_WARMUP_ITERATIONS
+        self.use_graph = graph_replay_enabled(cfg)
 
     def step(self):
+        """One attack iteration: a graph replay when captured, the eager body otherwise."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue_iteration()
+            if self.use_graph and self.iterations + 1 == self.capture_after:
+                self._capture()
+        self.iterations += 1
+
+    def disable_graph(self):
+        """Back to eager launches (bench.py uses this to time individual kernels with events)."""
+        self.graph, self.use_graph = None, False
+
+    def _capture(self):
+        device = self.device
+        try:
+            torch.cuda.synchronize(device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.device(device), torch.cuda.graph(graph):
+                self._enqueue_iteration()
+            self.graph = graph
+        except Exception as exc:  # stay on the eager HIP path; never leave the GPU
+            self.graph, self.use_graph, self.graph_failed = None, False, repr(exc)
+            log.warning(f"hipGraph capture of the attack iteration failed ({exc!r}); continuing with eager launches.")
+            torch.cuda.synchronize(device)
+
+    def _enqueue_iteration(self):
         lib, att, device = self.lib, self.attacker, self.device
         with torch.cuda.device(device):
             stream = _lib.current_stream_handle(device)
@@ -749,7 +795,6 @@ class FusedTrial:
                     "bh_candidate_step",
                 )
         att.current_task_loss = task_loss
-        self.iterations += 1
 
     def read_state(self):
         """Synchronising read of the trial record."""

@@ -334,13 +334,22 @@ int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
 
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, void* stream) {
+              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
+              void* ev_stop) {
   if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
       n_chunks <= 0 || group_chunk_begin == nullptr || partials_dev == nullptr)
     return BH_EINVAL;
   if (kind == BH_GM_TAG && weights_dev == nullptr) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   const int groups = bh_gm_num_groups(n_tensors);
+  for (int g = 0; g < groups; ++g) {  // validate every pointer before anything is enqueued
+    GmPtrs probe;
+    if (!fill_ptrs(probe, rec_ptrs, n_tensors, g)) return BH_EINVAL;
+  }
+  if (ev_start) {
+    const int rc = bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_start), st));
+    if (rc != 0) return rc;
+  }
   for (int g = 0; g < groups; ++g) {
     const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
     if (n <= 0) continue;
@@ -370,6 +379,7 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
     const int rc = bh::launch_status();
     if (rc != 0) return rc;
   }
+  if (ev_stop) return bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_stop), st));
   return 0;
 }
 
@@ -383,13 +393,22 @@ int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, flo
 
 int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, const float* stats_dev, const float* gout_dev, float* grad_flat, void* stream) {
+              const float* weights_dev, const float* stats_dev, const float* gout_dev, float* grad_flat, void* stream,
+              void* ev_start, void* ev_stop) {
   if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
       n_chunks <= 0 || group_chunk_begin == nullptr || stats_dev == nullptr || !aligned16(grad_flat))
     return BH_EINVAL;
   if (kind == BH_GM_TAG && weights_dev == nullptr) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   const int groups = bh_gm_num_groups(n_tensors);
+  for (int g = 0; g < groups; ++g) {  // validate every pointer before anything is enqueued
+    GmPtrs probe;
+    if (!fill_ptrs(probe, rec_ptrs, n_tensors, g)) return BH_EINVAL;
+  }
+  if (ev_start) {
+    const int rc = bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_start), st));
+    if (rc != 0) return rc;
+  }
   for (int g = 0; g < groups; ++g) {
     const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
     if (n <= 0) continue;
@@ -421,6 +440,7 @@ int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
     const int rc = bh::launch_status();
     if (rc != 0) return rc;
   }
+  if (ev_stop) return bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_stop), st));
   return 0;
 }
 

@@ -208,6 +208,31 @@ int bh_candidate_step(const void* state_dev, const double* sched_dev, const bh_s
   return bh::launch_status();
 }
 
+int bh_event_create(void** event_out) {
+  if (event_out == nullptr) return BH_EINVAL;
+  hipEvent_t ev = nullptr;
+  const int rc = bh::hip_status(hipEventCreate(&ev));
+  *event_out = rc == 0 ? static_cast<void*>(ev) : nullptr;
+  return rc;
+}
+
+int bh_event_destroy(void* event) {
+  if (event == nullptr) return BH_EINVAL;
+  return bh::hip_status(hipEventDestroy(static_cast<hipEvent_t>(event)));
+}
+
+int bh_event_record(void* event, void* stream) {
+  if (event == nullptr) return BH_EINVAL;
+  return bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(event), bh::as_stream(stream)));
+}
+
+int bh_event_elapsed_ms(void* start, void* stop, float* ms_out) {
+  if (start == nullptr || stop == nullptr || ms_out == nullptr) return BH_EINVAL;
+  int rc = bh::hip_status(hipEventSynchronize(static_cast<hipEvent_t>(stop)));
+  if (rc != 0) return rc;
+  return bh::hip_status(hipEventElapsedTime(ms_out, static_cast<hipEvent_t>(start), static_cast<hipEvent_t>(stop)));
+}
+
 int32_t bh_abi_version(void) { return BH_ABI_VERSION; }
 
 const char* bh_build_arch(void) { return "gfx950"; }

@@ -88,11 +88,31 @@ class GradientMatchPlan:
         self.timers = dict(fwd=[], bwd=[])
 
     def _timed(self, key):
-        if self.timers is None:
-            return None
-        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        """A fresh (start, stop) pair of hipEvent handles, recorded by the C side right around the launch."""
+        if self.timers is None or torch.cuda.is_current_stream_capturing():
+            return None, None
+        lib = _lib.load()
+        pair = (c_void_p(), c_void_p())
+        for ev in pair:
+            _lib.check(lib.bh_event_create(ctypes.byref(ev)), "bh_event_create")
         self.timers[key].append(pair)
         return pair
+
+    def drain_timers(self):
+        """Elapsed microseconds per recorded launch, per direction; destroys the events."""
+        lib = _lib.load()
+        out = {}
+        for key, pairs in (self.timers or {}).items():
+            vals = []
+            for a, b in pairs:
+                ms = ctypes.c_float(0)
+                _lib.check(lib.bh_event_elapsed_ms(a, b, ctypes.byref(ms)), "bh_event_elapsed_ms")
+                vals.append(ms.value * 1e3)
+                lib.bh_event_destroy(a)
+                lib.bh_event_destroy(b)
+            out[key] = vals
+        self.timers = None
+        return out
 
     # -- helpers ---------------------------------------------------------------------------------------------------
     def _prepare(self, tensors):
@@ -135,16 +155,12 @@ class GradientMatchPlan:
         stats = torch.empty(_lib.BH_GM_STAT_WORDS, dtype=torch.float32, device=self.device)
         stream = _lib.current_stream_handle(self.device)
         ptrs = self._pointer_array(rec)
-        pair = self._timed("fwd")
-        if pair:
-            pair[0].record()
+        ev0, ev1 = self._timed("fwd")
         _lib.check(
             lib.bh_gm_fwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(self.partials), stream),
+                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(self.partials), stream, ev0, ev1),
             "bh_gm_fwd",
         )
-        if pair:
-            pair[1].record()
         _lib.check(
             lib.bh_gm_finalize(kind, _lib.ptr(self.partials), self.n_chunks, float(scale), float(tag_scale), float(fudge),
                                _lib.ptr(stats), stream),
@@ -158,16 +174,12 @@ class GradientMatchPlan:
         grad_flat = torch.empty(max(self.flat_elems, 4), dtype=torch.float32, device=self.device)
         stream = _lib.current_stream_handle(self.device)
         ptrs = self._pointer_array(rec)
-        pair = self._timed("bwd")
-        if pair:
-            pair[0].record()
+        ev0, ev1 = self._timed("bwd")
         _lib.check(
             lib.bh_gm_bwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), _lib.ptr(stats), _lib.ptr(gout), _lib.ptr(grad_flat), stream),
+                          self._group_bounds, _lib.ptr(weights), _lib.ptr(stats), _lib.ptr(gout), _lib.ptr(grad_flat), stream, ev0, ev1),
             "bh_gm_bwd",
         )
-        if pair:
-            pair[1].record()
         return grad_flat
 
     def split(self, grad_flat):

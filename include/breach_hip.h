@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 1
+#define BH_ABI_VERSION 2
 #define BH_EINVAL (-1)
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -92,7 +92,11 @@ int bh_gm_build_table(int32_t n_tensors, const int64_t* numel, bh_gm_chunk* chun
  * reference: objectives.py:89-95, 133-141, 158-166, 183-196, 233-244, 259-273 (the list reductions). */
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, void* stream);
+              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
+              void* ev_stop);
+/* `ev_start` / `ev_stop` (here and in bh_gm_bwd): optional hipEvent_t handles from bh_event_create, recorded on
+ * `stream` immediately before the first and after the last launch of the call -- from C, back to back with the launch,
+ * so that a host-bound caller does not smear its own latency into the measurement.  NULL = no timing. */
 
 /* Number of launch groups for a list of n_tensors pointers: ceil(n_tensors / BH_GM_MAX_PTRS). */
 int32_t bh_gm_num_groups(int32_t n_tensors);
@@ -114,7 +118,8 @@ int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, flo
  * reference: the autograd graph of the functions listed at bh_gm_fwd. */
 int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, const float* stats_dev, const float* gout_dev, float* grad_flat, void* stream);
+              const float* weights_dev, const float* stats_dev, const float* gout_dev, float* grad_flat, void* stream,
+              void* ev_start, void* ev_stop);
 
 /* Pack a list of device tensors into the flat layout (used once per attack for the observed gradient).
  * reference: base_attack.py:214-220 (_cast_shared_data keeps a list; we keep one packed copy). */
@@ -222,6 +227,13 @@ typedef struct bh_step_params {
 int bh_candidate_step(const void* state_dev, const double* sched_dev, const bh_step_params* params, float* x,
                       const float* g, const float* g_reg, const float* noise, float* m, float* v, float* best,
                       void* stream);
+
+/* Timing helpers (thin wrappers over hipEvent*, used by bench.py for the roofline leg). */
+int bh_event_create(void** event_out);
+int bh_event_destroy(void* event);
+int bh_event_record(void* event, void* stream);
+/* Blocks until `stop` has completed, then writes the elapsed milliseconds between the two events. */
+int bh_event_elapsed_ms(void* start, void* stop, float* ms_out);
 
 /* Library / build introspection. */
 int32_t bh_abi_version(void);
