@@ -47,9 +47,9 @@ class StepParams(Structure):
         ("max_iterations", c_int32),
         ("lo", c_float * 4),
         ("hi", c_float * 4),
-        ("beta1", c_float),
-        ("beta2", c_float),
-        ("eps", c_float),
+        ("beta1", c_double),
+        ("beta2", c_double),
+        ("eps", c_double),
         ("decoupled_wd", c_int32),
         ("langevin", c_float),
         ("grad_clip", c_float),

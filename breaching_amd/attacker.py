@@ -743,6 +743,15 @@ class FusedTrial:
     def _capture(self):
         device = self.device
         try:
+            # Nothing from the eager iterations may keep an autograd graph alive: a surviving AccumulateGrad node is bound
+            # to the eager stream and capture would have to synchronise with it (ROCm 7.2 crashes in hipStreamEndCapture).
+            import gc
+
+            for reg in self.autograd_regs:
+                release = getattr(reg, "release_graph", None)
+                if release is not None:
+                    release()
+            gc.collect()
             torch.cuda.synchronize(device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.device(device), torch.cuda.graph(graph):

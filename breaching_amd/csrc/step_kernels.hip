@@ -123,8 +123,11 @@ __global__ __launch_bounds__(kBlock) void candidate_step_kernel(const Word* __re
   }
   // soft sign factor (:176-180): python evaluates 1 - iteration / max_iterations in double
   const float soft = (float)(1.0 - (double)it / (double)P.max_iterations);
-  const float w1 = (float)(1.0 - (double)P.beta1);
-  const float w2 = (float)(1.0 - (double)P.beta2);
+  // torch passes `1 - beta` (evaluated in double) and `beta2`, `eps` as Python scalars that become fp32 in the kernels
+  const float w1 = (float)(1.0 - P.beta1);
+  const float w2 = (float)(1.0 - P.beta2);
+  const float beta2 = (float)P.beta2;
+  const float eps = (float)P.eps;
 
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * kBlock) {
     float gr = effective_grad(g, g_reg, noise, noise_coef, i);
@@ -137,8 +140,8 @@ __global__ __launch_bounds__(kBlock) void candidate_step_kernel(const Word* __re
     float xi = x[i], mi = m[i], vi = v[i];
     if (P.decoupled_wd) xi *= decay;
     mi = fmaf(w1, gr - mi, mi);
-    vi = fmaf(w2 * gr, gr, vi * P.beta2);
-    const float denom = sqrtf(vi) / bc2_sqrt + P.eps;
+    vi = fmaf(w2 * gr, gr, vi * beta2);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
     xi = xi - (step_size * mi) / denom;
     if (P.boxed) {  // :117-118  max(min(x, hi), lo)
       const int c = (int)((i / P.plane) % P.channels);

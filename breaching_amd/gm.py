@@ -80,7 +80,6 @@ class GradientMatchPlan:
                                _lib.ptr(self.data_flat), _lib.current_stream_handle(self.device)),
                 "bh_gm_pack",
             )
-        self._keepalive = None
         # optional per-launch timing (bench.py): lists of (start, end) torch.cuda.Event pairs on the launch stream
         self.timers = None
 
@@ -141,7 +140,8 @@ class GradientMatchPlan:
                 # only reachable for the observed gradient at pack time; make an aligned copy
                 tensors[i] = tensors[i].clone(memory_format=torch.contiguous_format)
                 addrs[i] = tensors[i].data_ptr()
-        self._keepalive = tensors
+        # No reference to `tensors` is kept: launches are stream ordered, and holding this iteration's gradients (which
+        # carry their autograd graph) would keep stale AccumulateGrad nodes alive and break hipGraph capture.
         return (c_void_p * len(addrs))(*addrs)
 
     def matches(self, gradient_data):

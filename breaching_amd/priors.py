@@ -212,6 +212,12 @@ class HipDeepInversion(torch.nn.Module):
                 if isinstance(module, torch.nn.BatchNorm2d):
                     self.losses[idx].append(_BnStatHook(module))
 
+    def release_graph(self):
+        """Drop the feature statistics of the last forward pass (they hold that pass's autograd graph)."""
+        for hooks in self.losses:
+            for hook in hooks:
+                hook.r_feature = None
+
     def forward(self, tensor, *args, **kwargs):
         feature_reg = 0
         for hooks in self.losses:

@@ -214,7 +214,7 @@ typedef struct bh_step_params {
   int32_t max_iterations; /* for the soft-sign factor 1 - it/max_iterations */
   float lo[4];
   float hi[4];
-  float beta1, beta2, eps;
+  double beta1, beta2, eps; /* doubles: torch derives 1-beta in double before rounding to fp32 (1 - 0.999f is 1.3e-5 off) */
   int32_t decoupled_wd; /* AdamW: x *= sched[2] first                      common.py:10-12 */
   float langevin;       /* langevin_noise (0 = off); noise must be non-NULL when > 0   :167-170 */
   float grad_clip;      /* <= 0 = off; uses state[BH_STATE_GNORM]                       :171-174 */

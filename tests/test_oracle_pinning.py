@@ -135,7 +135,8 @@ def _compare(prefix, gold, rec, stats, case, crop=None, exact=True):
     data = rec["data"].numpy()
     if crop is not None:
         data = data[..., :crop, :crop]
-    assert np.isclose(data, gold[f"{prefix}rec"], rtol=1e-4, atol=1e-4).mean() > 0.999
+    tol = 1e-4 if exact else 2e-3
+    assert np.isclose(data, gold[f"{prefix}rec"], rtol=tol, atol=tol).mean() > (0.999 if exact else 0.99)
 
 
 def test_restatement_convnet_invertinggradients(golden_dir):
@@ -145,7 +146,7 @@ def test_restatement_convnet_invertinggradients(golden_dir):
     torch.set_num_threads(8)
     gold = _gold(golden_dir, "attack_convnet.npz")
     case = _cpu_case("convnet", "CIFAR10", 1)
-    x0 = initial_candidate(case.data_cfg, 1)
+    x0 = initial_candidate(case.data_cfg, 1, seed=int(gold["x0_seed"]))
     rec, stats = _run_restatement(case, get_attack_config("invertinggradients", ["optim.max_iterations=100", "optim.callback=50"]), x0)
     _compare("", gold, rec, stats, case)
     rec, stats = _run_restatement(case, get_attack_config("invertinggradients", ["optim.max_iterations=100"]), x0, dryrun=True)
@@ -160,7 +161,7 @@ def test_restatement_convnet_euclidean_softsign(golden_dir):
     torch.set_num_threads(8)
     gold = _gold(golden_dir, "attack_convnet.npz")
     case = _cpu_case("convnet", "CIFAR10", 1)
-    x0 = initial_candidate(case.data_cfg, 1)
+    x0 = initial_candidate(case.data_cfg, 1, seed=int(gold["x0_seed"]))
     cfg = get_attack_config("invertinggradients", [
         "objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft", "optim.step_size_decay=cosine-decay",
         "optim.warmup=5", "optim.max_iterations=40", "restarts.scoring=euclidean", "regularization.norm.scale=0.01",
