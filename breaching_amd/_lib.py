@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from . import build as _build
 
 # ---- constants mirrored from include/breach_hip.h (checked against the library in tests) -------------------------
-BH_ABI_VERSION = 2
+BH_ABI_VERSION = 3
 BH_GM_CHUNK = 4096
 BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
@@ -69,7 +69,8 @@ _PROTOTYPES = {
         [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p, c_void_p,
          c_void_p, c_void_p],
     ),
-    "bh_gm_finalize": (c_int, [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_void_p, c_void_p]),
+    "bh_gm_finalize": (c_int, [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "bh_wall_clock_khz": (c_int32, []),
     "bh_gm_bwd": (
         c_int,
         [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -144,7 +144,7 @@ _ATTACKS = {
         type="deep-leakage",
         attack_type="joint-optimization",
         label_strategy="None",
-        objective=dict(type="euclidean", scale=1.0),
+        token_recovery="from-embedding",
         optim=dict(optimizer="L-BFGS", step_size=1.0, boxed=False, max_iterations=1200, callback=100),
     ),
 }

@@ -61,10 +61,12 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
                                                         double* __restrict__ partials) {
   __shared__ double lds[bh::kWavesPerBlock * 3];
   const int c = chunk_base + blockIdx.x;
+  const int tid = threadIdx.x;
+  // constant-rate wall clock at block entry (thread 0 only): lets the finalize kernel report the launch's true span
+  const unsigned int tick0 = tid == 0 ? (unsigned int)wall_clock64() : 0u;
   const bh_gm_chunk ch = chunks[c];
   const float* __restrict__ r = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
   const float* __restrict__ d = data_flat + ch.flat_off;
-  const int tid = threadIdx.x;
 
   // two independent accumulator sets keep the fma chains short
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -100,23 +102,45 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
     }
     row[1] = v[1];
     row[2] = v[2];
+    const unsigned long long packed = ((unsigned long long)tick0 << 32) | (unsigned int)wall_clock64();
+    row[3] = __longlong_as_double((long long)packed);
   }
 }
 
 // Single workgroup: fixed-order sum of the partial rows, then the objective epilogue.
 __global__ __launch_bounds__(kBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials, int64_t n_rows,
                                                              float scale, float tag_scale, float fudge,
-                                                             float* __restrict__ stats) {
+                                                             float* __restrict__ stats, double* __restrict__ span_accum) {
   __shared__ double lds[bh::kWavesPerBlock * 3];
+  __shared__ int span_lds[2 * kBlock];
   double v[3] = {0.0, 0.0, 0.0};
+  // span of the forward launch in wall-clock ticks: max(end) - min(start), relative to row 0 (wrap safe: 32-bit deltas)
+  const unsigned int base_tick =
+      (unsigned int)((unsigned long long)__double_as_longlong(partials[BH_GM_PARTIAL_STRIDE - 1]) >> 32);
+  int lo = 0x7fffffff, hi = -0x7fffffff;
   for (int64_t row = threadIdx.x; row < n_rows; row += kBlock) {
     const double* p = partials + row * BH_GM_PARTIAL_STRIDE;
     v[0] += p[0];
     v[1] += p[1];
     v[2] += p[2];
+    const unsigned long long packed = (unsigned long long)__double_as_longlong(p[3]);
+    const int t0 = (int)((unsigned int)(packed >> 32) - base_tick), t1 = (int)((unsigned int)packed - base_tick);
+    lo = t0 < lo ? t0 : lo;
+    hi = t1 > hi ? t1 : hi;
   }
-  bh::block_sum<3>(v, lds);
+  span_lds[threadIdx.x] = lo;
+  span_lds[kBlock + threadIdx.x] = hi;
+  bh::block_sum<3>(v, lds);  // contains the __syncthreads() that also publishes span_lds
   if (threadIdx.x != 0) return;
+  for (int t = 1; t < kBlock; ++t) {
+    lo = span_lds[t] < lo ? span_lds[t] : lo;
+    hi = span_lds[kBlock + t] > hi ? span_lds[kBlock + t] : hi;
+  }
+  const float span_ticks = (float)(hi - lo);
+  if (span_accum) {  // running sum / count for bench.py (works under hipGraph replay, no host involvement)
+    span_accum[0] += (double)span_ticks;
+    span_accum[1] += 1.0;
+  }
   const double s = (double)scale;
   double loss = 0.0, c1 = 0.0, c2 = 0.0;
   if (kind <= BH_GM_ANGULAR) {
@@ -159,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void gm_finalize_kernel(int kind, const dou
   stats[BH_GM_STAT_S0] = (float)v[0];
   stats[BH_GM_STAT_S1] = (float)v[1];
   stats[BH_GM_STAT_S2] = (float)v[2];
-  stats[6] = 0.f;
+  stats[BH_GM_STAT_SPAN_TICKS] = span_ticks;
   stats[7] = 0.f;
 }
 
@@ -384,11 +408,18 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
 }
 
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
-                   float* stats_dev, void* stream) {
+                   float* stats_dev, double* span_accum_dev, void* stream) {
   if (!valid_kind(kind) || partials_dev == nullptr || n_rows <= 0 || stats_dev == nullptr) return BH_EINVAL;
   hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), kind, partials_dev, n_rows,
-                     scale, tag_scale, fudge, stats_dev);
+                     scale, tag_scale, fudge, stats_dev, span_accum_dev);
   return bh::launch_status();
+}
+
+int32_t bh_wall_clock_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return BH_EINVAL;
+  if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return BH_EINVAL;
+  return khz;
 }
 
 int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,

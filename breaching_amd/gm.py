@@ -80,8 +80,18 @@ class GradientMatchPlan:
                                _lib.ptr(self.data_flat), _lib.current_stream_handle(self.device)),
                 "bh_gm_pack",
             )
-        # optional per-launch timing (bench.py): lists of (start, end) torch.cuda.Event pairs on the launch stream
+        # optional per-launch timing (bench.py): lists of (start, end) hipEvent pairs on the launch stream
         self.timers = None
+        # device-side running [sum of forward-launch spans in wall-clock ticks, launches]; bench.py zeroes / reads it
+        self.span_accum = torch.zeros(2, dtype=torch.float64, device=self.device)
+
+    def forward_span_us(self, reset=False):
+        """Average span of the forward launches since the last reset, from the device wall clock (synchronises)."""
+        total, count = self.span_accum.cpu().tolist()
+        if reset:
+            self.span_accum.zero_()
+        khz = _lib.load().bh_wall_clock_khz()
+        return (total / count) / (khz / 1e3) if count > 0 and khz > 0 else None, int(count)
 
     def enable_timing(self):
         self.timers = dict(fwd=[], bwd=[])
@@ -163,7 +173,7 @@ class GradientMatchPlan:
         )
         _lib.check(
             lib.bh_gm_finalize(kind, _lib.ptr(self.partials), self.n_chunks, float(scale), float(tag_scale), float(fudge),
-                               _lib.ptr(stats), stream),
+                               _lib.ptr(stats), _lib.ptr(self.span_accum), stream),
             "bh_gm_finalize",
         )
         return stats

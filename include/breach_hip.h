@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 2
+#define BH_ABI_VERSION 3
 #define BH_EINVAL (-1)
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -69,6 +69,7 @@ enum bh_gm_stat {
   BH_GM_STAT_S0 = 3,   /* raw sums: cosine family <r,d>, |r|^2, |d|^2 ; L2 family  sum (r-d)^2, sum |r-d|, - */
   BH_GM_STAT_S1 = 4,
   BH_GM_STAT_S2 = 5,
+  BH_GM_STAT_SPAN_TICKS = 6, /* wall-clock ticks between the first block entering and the last block leaving bh_gm_fwd */
   BH_GM_STAT_WORDS = 8
 };
 
@@ -109,7 +110,12 @@ int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
  * reference: objectives.py:95 (0.5*objective), :141, :166, :195, :211-214, :243, :271 and the `* self.scale`
  * at :86, :126, :155, :178. */
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
-                   float* stats_dev, void* stream);
+                   float* stats_dev, double* span_accum_dev, void* stream);
+/* Every forward workgroup stamps the constant-rate device wall clock (bh_wall_clock_khz) on entry and exit into the
+ * spare word of its partial row; the finalize kernel reduces them to the launch's span (stats[BH_GM_STAT_SPAN_TICKS])
+ * and, when `span_accum_dev` is non-NULL, adds it to span_accum_dev[0] and 1 to span_accum_dev[1] (doubles).  This is how
+ * bench.py times kernel A *inside* hipGraph replays, where host-visible event pairs cannot be placed. */
+int32_t bh_wall_clock_khz(void);
 
 /* Backward: d objective / d rec_i for every tensor, written into the packed layout `grad_flat` (same offsets as
  * data_flat), multiplied by the upstream scalar *gout_dev (NULL means 1).

@@ -1,0 +1,58 @@
+"""Condense rocprofv3 CSV output into small summaries that fit gpurun's copy-back limit and profiles/.
+
+    python scripts/summarize_prof.py <rocprof_dir> <out_prefix> [pmc_counter_name]
+"""
+import csv, os, sys, collections
+
+OURS = ("gm_fwd_kernel", "gm_bwd_kernel", "gm_finalize_kernel", "tv_norm_kernel", "candidate_step_kernel", "loss_commit_kernel",
+        "bnstat_", "grad_sumsq", "gm_pack_kernel", "state_reset")
+src, out = sys.argv[1], sys.argv[2]
+counter = sys.argv[3] if len(sys.argv) > 3 else None
+files = {f: os.path.join(src, f) for f in os.listdir(src)}
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "")[:90]
+
+
+trace = next((p for f, p in files.items() if f.endswith("kernel_trace.csv")), None)
+if trace:
+    per = collections.defaultdict(list)
+    first, last = None, None
+    with open(trace) as f:
+        for row in csv.DictReader(f):
+            s, e = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+            per[row["Kernel_Name"]].append(e - s)
+            first = s if first is None else min(first, s)
+            last = e if last is None else max(last, e)
+    total = sum(sum(v) for v in per.values())
+    rows = sorted(per.items(), key=lambda kv: -sum(kv[1]))
+    with open(out + "_kernel_summary.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct_of_kernel_time", "ours"])
+        for name, d in rows:
+            w.writerow([short(name), len(d), round(sum(d) / 1e3, 2), round(sum(d) / len(d) / 1e3, 3), round(min(d) / 1e3, 3),
+                        round(max(d) / 1e3, 3), round(100 * sum(d) / total, 2), int(any(k in name for k in OURS))])
+    with open(out + "_kernel_summary.txt", "w") as f:
+        f.write(f"kernels: {sum(len(v) for v in per.values())} dispatches, {len(per)} distinct, busy {total/1e6:.2f} ms over a span of {(last-first)/1e6:.2f} ms\n")
+        for name, d in rows:
+            if any(k in name for k in OURS):
+                f.write(f"{short(name):70s} calls={len(d):5d} avg={sum(d)/len(d)/1e3:8.2f}us min={min(d)/1e3:8.2f}us max={max(d)/1e3:8.2f}us\n")
+    print(open(out + "_kernel_summary.txt").read())
+
+cc = next((p for f, p in files.items() if f.endswith("counter_collection.csv")), None)
+if cc:
+    per = collections.defaultdict(list)
+    with open(cc) as f:
+        for row in csv.DictReader(f):
+            if counter and row.get("Counter_Name") != counter:
+                continue
+            per[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
+    with open(out + "_pmc_summary.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatches", "avg_value", "min_value", "max_value"])
+        for (name, cn), d in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+            if any(k in name for k in OURS):
+                w.writerow([short(name), cn, len(d), round(sum(d) / len(d), 3), min(d), max(d)])
+    print(open(out + "_pmc_summary.csv").read())

@@ -1,0 +1,140 @@
+"""Host-side logic that needs no GPU: score keys, trial sharding over gloo (world size 2), config plumbing."""
+
+import math
+import os
+import random
+import socket
+import struct
+
+import pytest
+import torch
+
+
+def test_score_key_orders_like_floats():
+    from breaching_amd.trials import score_key, unpack_key
+
+    rng = random.Random(0)
+    scores = [0.0, 1e-30, 1e-8, 0.007, 0.5, 1.0, 1.9999, 2.0, 649.24, 3e38, float("inf")] + [rng.random() * 10 for _ in range(200)]
+    items = [(s, t) for t, s in enumerate(scores)]
+    by_key = sorted(items, key=lambda it: score_key(it[0], it[1]))
+    by_float = sorted(items, key=lambda it: (struct.unpack("<f", struct.pack("<f", it[0]))[0], it[1]))
+    assert by_key == by_float
+    s, t = unpack_key(score_key(0.0987, 31))
+    assert t == 31 and abs(s - 0.0987) < 1e-8
+    # NaN is treated as +inf, exactly like `score if score.isfinite() else inf` (optimization_based_attack.py:204)
+    assert score_key(float("nan"), 3) == score_key(float("inf"), 3)
+    assert score_key(0.5, 7) < score_key(0.5, 8)  # ties resolve to the lower trial like torch.min's first index
+    assert score_key(1.0, 0) < 2**63
+
+
+def test_trial_shard_partition():
+    from breaching_amd.trials import TrialShard
+
+    seen = []
+    for rank in range(8):
+        seen += list(TrialShard(32, rank, 8).local_trials())
+        assert len(list(TrialShard(32, rank, 8).local_trials())) == 4
+    assert sorted(seen) == list(range(32))
+    assert list(TrialShard(3, 2, 8).local_trials()) == [2]
+    assert list(TrialShard(3, 5, 8).local_trials()) == []
+    assert list(TrialShard(5).local_trials()) == [0, 1, 2, 3, 4]
+
+
+def test_single_process_selection_matches_reference_argmin():
+    from breaching_amd.trials import TrialShard
+
+    sols = {t: torch.full((2, 2), float(t)) for t in range(4)}
+    scores = {0: torch.tensor([0.4]), 1: 0.3, 2: float("inf"), 3: torch.tensor(0.3)}
+    value, sol = TrialShard(4).select(sols, scores, {}, torch.device("cpu"))
+    assert value == pytest.approx(0.3) and sol is sols[1]
+    value, sol = TrialShard(2).select({0: sols[0], 1: sols[1]}, {0: float("nan"), 1: float("inf")}, {}, torch.device("cpu"))
+    assert math.isinf(value)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, num_trials, out_dir):
+    import torch.distributed as dist
+
+    from breaching_amd.trials import TrialShard
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = TrialShard.current(num_trials)
+        assert (shard.rank, shard.world) == (rank, world)
+        gen = torch.Generator().manual_seed(0)
+        all_scores = torch.rand(num_trials, generator=gen)
+        if num_trials > 3:
+            all_scores[3] = float("inf")
+        sols, scores, stats = {}, {}, {}
+        for t in shard.local_trials():
+            sols[t] = (torch.full((1, 3, 4, 4), float(t)), torch.full((1, 5), float(-t)))  # joint attacker: tuple
+            scores[t] = all_scores[t]
+            stats[f"Trial_{t}_Val"] = [float(t)] * (t + 1)
+        value, sol = shard.select(sols, scores, stats, torch.device("cpu"))
+        torch.save(dict(value=value, data=sol[0], labels=sol[1], stats=stats, expect=int(all_scores.argmin()),
+                        expect_value=float(all_scores.min())), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_trials", [5, 2, 1])
+def test_two_rank_gloo_selection(tmp_path, num_trials):
+    """World size 2 on CPU (gloo): every rank ends with the same winner, the winner's tensors and all trial stats."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, num_trials, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(2))
+    for r in (r0, r1):
+        assert r["value"] == pytest.approx(r["expect_value"])
+        assert float(r["data"].flatten()[0]) == float(r["expect"])
+        assert float(r["labels"].flatten()[0]) == -float(r["expect"])
+        assert sorted(r["stats"]) == [f"Trial_{t}_Val" for t in range(num_trials)]
+        for t in range(num_trials):
+            assert r["stats"][f"Trial_{t}_Val"] == [float(t)] * (t + 1)
+    assert r0["value"] == r1["value"]
+
+
+def test_config_overrides_and_attrdict():
+    from breaching_amd.config import AttrDict, get_attack_config
+
+    cfg = get_attack_config("invertinggradients", ["optim.max_iterations=7", "regularization.total_variation.scale=0.5",
+                                                   "optim.step_size_decay=null", "restarts.num_trials=4"])
+    assert cfg.optim.max_iterations == 7 and cfg["optim"]["step_size_decay"] is None
+    assert cfg.regularization.total_variation.scale == 0.5 and cfg.restarts.num_trials == 4
+    assert dict(**cfg.objective) == dict(type="cosine-similarity", scale=1.0, task_regularization=0.0)
+    assert list(cfg.regularization.keys()) == ["total_variation"]
+    assert isinstance(cfg.optim, AttrDict)
+    with pytest.raises(ValueError):
+        get_attack_config("does-not-exist")
+    untouched = get_attack_config("invertinggradients")
+    assert untouched.optim.max_iterations == 24_000  # overrides never leak into the templates
+
+
+def test_optimizer_lookup_names():
+    from breaching_amd.schedules import optimizer_hparams
+
+    assert optimizer_hparams("Adam")["eps"] == 1e-8
+    assert optimizer_hparams("bert-adam") == dict(betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01, decoupled=True)
+    assert optimizer_hparams("L-BFGS") is None and optimizer_hparams("momGD") is None
+    with pytest.raises(ValueError):
+        optimizer_hparams("adagrad")
+
+
+def test_adam_schedule_table_matches_torch_scalars():
+    from breaching_amd.schedules import adam_schedule_table
+
+    table = adam_schedule_table([0.1, 0.05, 0.0], 0.9, 0.999, 0.01)
+    for k, lr in enumerate([0.1, 0.05, 0.0]):
+        step = k + 1
+        assert table[k, 0] == lr / (1 - 0.9**step)
+        assert table[k, 1] == (1 - 0.999**step) ** 0.5
+        assert table[k, 2] == 1 - lr * 0.01 and table[k, 3] == lr
