@@ -61,6 +61,8 @@ def parse_args():
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in the timed region")
     p.add_argument("--roofline-steps", type=int, default=40, help="eager iterations with per-launch HIP events")
+    p.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
+    p.add_argument("--channels-last", action="store_true", help="victim model and candidate in NHWC memory format")
     return p.parse_args()
 
 
@@ -83,9 +85,19 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for single-GPU plumbing checks
+    if "BENCH_DEVICE_INDEX" in os.environ:  # several ranks on one GPU (functional check of the N > 1 path on a 1-GPU box)
+        local_rank = int(os.environ["BENCH_DEVICE_INDEX"])
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if args.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
 
     # ---- workload --------------------------------------------------------------------------------------------------
     torch.manual_seed(0)
@@ -97,7 +109,12 @@ def main():
     attacker.objective.initialize(attacker.loss_fn, cfg.impl, None)
     for reg in attacker.regularizers:
         reg.initialize(rec_models, case.shared_data, labels)
-    x0 = initial_candidate(case.data_cfg, 1, trial=rank).to(device).requires_grad_(True)
+    x0 = initial_candidate(case.data_cfg, 1, trial=rank).to(device)
+    if args.channels_last:
+        for m in rec_models:
+            m.to(memory_format=torch.channels_last)
+        x0 = x0.contiguous(memory_format=torch.channels_last)
+    x0 = x0.requires_grad_(True)
     run = FusedTrial(attacker, [x0], labels, rec_models, case.shared_data)
     n_elements = sum(p.numel() for p in rec_models[0].parameters())
 
@@ -124,7 +141,7 @@ def main():
     elapsed = time.perf_counter() - t0
     span_us, span_launches = plan.forward_span_us() if plan is not None else (None, 0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     mode = "hipGraph replay" if run.graph is not None else "eager launches"
@@ -156,19 +173,31 @@ def main():
                 avg_us = sum(us) / len(us)
                 kernels[key] = dict(avg_us=avg_us, median_us=us[len(us) // 2], min_us=us[0], launches=len(us),
                                     algorithmic_bytes=bytes_per, achieved_GBs=bytes_per / (avg_us * 1e-6) / 1e9)
-    # Primary figure: device wall-clock span of every kernel-A forward launch INSIDE the timed region (works under graph
-    # replay); the HIP-event pairs above are the cross-check, the rocprofv3 kernel trace in profiles/ the reference.
+    # Kernel A forward: average launch duration from HIP events (hipExtLaunchKernelGGL start/stop events = the dispatch's
+    # own begin/end timestamps, the quantity rocprofv3 reports).  A replayed graph cannot carry events, so when the timed
+    # region ran as graph replays they come from the eager continuation right after it, and the device wall-clock span
+    # (first workgroup in -> last workgroup out) of every launch INSIDE the timed region is reported next to them.
     fwd_bytes = 2 * n_elements * 4
-    if span_us:
+    if "fwd" in kernels:
+        k = kernels["fwd"]
+        roofline = dict(bound="hbm", kernel="gm_fwd_kernel<cosine>", achieved=round(k["achieved_GBs"], 1), peak=HBM_PEAK_GBS,
+                        unit="GB/s", frac=round(k["achieved_GBs"] / HBM_PEAK_GBS, 4), traffic=pmc_traffic_bytes("gm_fwd_kernel"),
+                        avg_launch_us=round(k["avg_us"], 2), launches=k["launches"], algorithmic_bytes=fwd_bytes,
+                        measured="HIP start/stop events of hipExtLaunchKernelGGL on the launch stream, " +
+                                 ("inside the timed region" if timed_with_events else
+                                  f"{args.roofline_steps} eager iterations continuing the timed graph-replay region"),
+                        timed_region_span_us=None if not span_us else round(span_us, 2),
+                        timed_region_span_launches=span_launches,
+                        timed_region_span_GBs=None if not span_us else round(fwd_bytes / (span_us * 1e-6) / 1e9, 1))
+    elif span_us:
         achieved = fwd_bytes / (span_us * 1e-6) / 1e9
         roofline = dict(bound="hbm", kernel="gm_fwd_kernel<cosine>", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic_bytes("gm_fwd_kernel"),
                         avg_launch_us=round(span_us, 2), launches=span_launches, algorithmic_bytes=fwd_bytes,
-                        measured="device wall clock (first workgroup in -> last workgroup out) of every launch in the timed region",
-                        hip_event_avg_us=round(kernels["fwd"]["avg_us"], 2) if "fwd" in kernels else None,
-                        hip_event_median_us=round(kernels["fwd"]["median_us"], 2) if "fwd" in kernels else None,
-                        hip_event_region=("timed region" if timed_with_events else
-                                          f"{args.roofline_steps} eager iterations right after the graph-replay timed region"))
+                        measured="device wall clock (first workgroup in -> last workgroup out) of every launch in the timed region")
+    if "bwd" in kernels:
+        kernels["bwd"]["traffic"] = pmc_traffic_bytes("gm_bwd_kernel")
+        kernels["bwd"]["frac_of_hbm_peak"] = round(kernels["bwd"]["achieved_GBs"] / HBM_PEAK_GBS, 4)
 
     # ---- trial selection: the one collective of the multi-GPU path --------------------------------------------------
     select_ms = None

@@ -15,6 +15,8 @@
 
 #include "bh_common.h"
 
+#include <hip/hip_ext.h>
+
 namespace {
 
 using bh::kBlock;
@@ -282,18 +284,41 @@ bool fill_ptrs(GmPtrs& out, const void* const* ptrs, int n_tensors, int g) {
 
 bool aligned16(const void* p) { return p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Timed launches go through hipExtLaunchKernelGGL: the two events then carry the dispatch's own start / end
+// timestamps (the same completion-signal times rocprofv3 reports), free of host latency and marker overhead.
+struct LaunchEvents {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+
 template <int KIND>
 void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
-                int n, const float* weights, float tag_scale, double* partials, hipStream_t st) {
-  hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
-                     chunk_base, weights, tag_scale, partials);
+                int n, const float* weights, float tag_scale, double* partials, hipStream_t st, LaunchEvents ev) {
+  if (ev.start || ev.stop)
+    hipExtLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
+                          data_flat, chunks, chunk_base, weights, tag_scale, partials);
+  else
+    hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+                       chunk_base, weights, tag_scale, partials);
 }
 
 template <int KIND>
 void launch_bwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
-                int n, const float* weights, const float* stats, const float* gout, float* grad_flat, hipStream_t st) {
-  hipLaunchKernelGGL(gm_bwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
-                     chunk_base, weights, stats, gout, grad_flat);
+                int n, const float* weights, const float* stats, const float* gout, float* grad_flat, hipStream_t st,
+                LaunchEvents ev) {
+  if (ev.start || ev.stop)
+    hipExtLaunchKernelGGL(gm_bwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
+                          data_flat, chunks, chunk_base, weights, stats, gout, grad_flat);
+  else
+    hipLaunchKernelGGL(gm_bwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+                       chunk_base, weights, stats, gout, grad_flat);
+}
+
+// events of launch group g out of `groups`: start on the first non-empty group, stop on the last
+LaunchEvents group_events(void* ev_start, void* ev_stop, bool first, bool last) {
+  LaunchEvents ev;
+  if (first) ev.start = static_cast<hipEvent_t>(ev_start);
+  if (last) ev.stop = static_cast<hipEvent_t>(ev_stop);
+  return ev;
 }
 
 }  // namespace
@@ -370,40 +395,36 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
     GmPtrs probe;
     if (!fill_ptrs(probe, rec_ptrs, n_tensors, g)) return BH_EINVAL;
   }
-  if (ev_start) {
-    const int rc = bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_start), st));
-    if (rc != 0) return rc;
-  }
   for (int g = 0; g < groups; ++g) {
     const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
     if (n <= 0) continue;
     GmPtrs ptrs;
     if (!fill_ptrs(ptrs, rec_ptrs, n_tensors, g)) return BH_EINVAL;
     const int tb = g * BH_GM_MAX_PTRS;
+    const LaunchEvents ev = group_events(ev_start, ev_stop, begin == 0, group_chunk_begin[g + 1] == n_chunks);
     switch (kind) {
       case BH_GM_COSINE:
       case BH_GM_COSINE_FAST:
       case BH_GM_ANGULAR:
-        launch_fwd<BH_GM_COSINE>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        launch_fwd<BH_GM_COSINE>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
         break;
       case BH_GM_COSINE_MASKED:
         launch_fwd<BH_GM_COSINE_MASKED>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev,
-                                        st);
+                                        st, ev);
         break;
       case BH_GM_L2:
-        launch_fwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        launch_fwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
         break;
       case BH_GM_L1:
-        launch_fwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        launch_fwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
         break;
       default:
-        launch_fwd<BH_GM_TAG>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st);
+        launch_fwd<BH_GM_TAG>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
         break;
     }
     const int rc = bh::launch_status();
     if (rc != 0) return rc;
   }
-  if (ev_stop) return bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_stop), st));
   return 0;
 }
 
@@ -436,42 +457,38 @@ int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
     GmPtrs probe;
     if (!fill_ptrs(probe, rec_ptrs, n_tensors, g)) return BH_EINVAL;
   }
-  if (ev_start) {
-    const int rc = bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_start), st));
-    if (rc != 0) return rc;
-  }
   for (int g = 0; g < groups; ++g) {
     const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
     if (n <= 0) continue;
     GmPtrs ptrs;
     if (!fill_ptrs(ptrs, rec_ptrs, n_tensors, g)) return BH_EINVAL;
     const int tb = g * BH_GM_MAX_PTRS;
+    const LaunchEvents ev = group_events(ev_start, ev_stop, begin == 0, group_chunk_begin[g + 1] == n_chunks);
     switch (kind) {
       case BH_GM_COSINE:
       case BH_GM_COSINE_FAST:
       case BH_GM_ANGULAR:
         launch_bwd<BH_GM_COSINE>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat,
-                                 st);
+                                 st, ev);
         break;
       case BH_GM_COSINE_MASKED:
         launch_bwd<BH_GM_COSINE_MASKED>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev,
-                                        grad_flat, st);
+                                        grad_flat, st, ev);
         break;
       case BH_GM_L2:
-        launch_bwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st);
+        launch_bwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st, ev);
         break;
       case BH_GM_L1:
-        launch_bwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st);
+        launch_bwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st, ev);
         break;
       default:
         launch_bwd<BH_GM_TAG>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat,
-                              st);
+                              st, ev);
         break;
     }
     const int rc = bh::launch_status();
     if (rc != 0) return rc;
   }
-  if (ev_stop) return bh::hip_status(hipEventRecord(static_cast<hipEvent_t>(ev_stop), st));
   return 0;
 }
 

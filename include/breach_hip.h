@@ -95,9 +95,10 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
               const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
               void* ev_stop);
-/* `ev_start` / `ev_stop` (here and in bh_gm_bwd): optional hipEvent_t handles from bh_event_create, recorded on
- * `stream` immediately before the first and after the last launch of the call -- from C, back to back with the launch,
- * so that a host-bound caller does not smear its own latency into the measurement.  NULL = no timing. */
+/* `ev_start` / `ev_stop` (here and in bh_gm_bwd): optional hipEvent_t handles from bh_event_create.  When given, the
+ * launch goes through hipExtLaunchKernelGGL, so the events carry the dispatch's own begin / end timestamps (the
+ * completion-signal times rocprofv3 reports) -- no host latency, no marker overhead.  Not usable during stream
+ * capture.  NULL = plain launch. */
 
 /* Number of launch groups for a list of n_tensors pointers: ceil(n_tensors / BH_GM_MAX_PTRS). */
 int32_t bh_gm_num_groups(int32_t n_tensors);
