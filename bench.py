@@ -83,13 +83,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for single-GPU plumbing checks
     if "BENCH_DEVICE_INDEX" in os.environ:  # several ranks on one GPU (functional check of the N > 1 path on a 1-GPU box)
         local_rank = int(os.environ["BENCH_DEVICE_INDEX"])
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":

@@ -226,3 +226,67 @@ def psnr(reconstruction, truth, data_cfg):
     if bool((mse == 0).any()):
         return float("inf")
     return float((10 * torch.log10(1.0 / mse)).mean())
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# text case (BASELINE config 5 family: BERT masked-LM + TAG joint attack)
+# -----------------------------------------------------------------------------------------------------------------
+class TokenModel(torch.nn.Module):
+    """Uniform call interface around a HuggingFace masked-LM: integer inputs are token ids, floating inputs are taken as
+    already-embedded tokens (what the attacker optimises after cutting off the embedding layer).  Same contract as the
+    reference's ``HuggingFaceContainer`` (model_preparation.py:134-149)."""
+
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, inputs):
+        if inputs.dtype == torch.long:
+            out = self.model(input_ids=inputs)
+        else:
+            out = self.model(inputs_embeds=inputs)
+        return out["logits"]
+
+
+class MaskedLMLoss(torch.nn.Module):
+    """Cross entropy over flattened tokens for integer or soft (probability) targets (losses.py:29-42)."""
+
+    def __init__(self, vocab_size):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.ce = torch.nn.CrossEntropyLoss()
+
+    def forward(self, outputs, labels):
+        target = labels.view(-1) if labels.dtype == torch.long else labels.view(-1, self.vocab_size)
+        return self.ce(outputs.view(-1, self.vocab_size), target)
+
+
+def build_text_case(device="cpu", vocab_size=300, seq_len=8, hidden=64, layers=2, heads=2, seed_model=0, seed_data=1,
+                    full_size=False):
+    """Random-init BERT masked-LM (tiny by default, bert-base sized with ``full_size``), one sequence of random tokens,
+    labels = tokens, user labels withheld (the joint attacker optimises them)."""
+    from transformers import BertConfig, BertForMaskedLM
+
+    torch.manual_seed(seed_model)
+    if full_size:
+        cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager")
+        vocab_size = cfg.vocab_size
+    else:
+        cfg = BertConfig(vocab_size=vocab_size, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
+                         intermediate_size=2 * hidden, max_position_embeddings=max(32, seq_len), hidden_dropout_prob=0.0,
+                         attention_probs_dropout_prob=0.0, attn_implementation="eager")
+    model = TokenModel(BertForMaskedLM(cfg))
+    model.eval()
+    loss_fn = MaskedLMLoss(vocab_size)
+    tokens = torch.randint(0, vocab_size, (1, seq_len), generator=torch.Generator().manual_seed(seed_data))
+    loss = loss_fn(model(tokens), tokens)
+    grads = torch.autograd.grad(loss, tuple(model.parameters()))
+    device = torch.device(device)
+    model = model.to(device)
+    data_cfg = AttrDict(name="synthetic-text", modality="text", task="masked-lm", vocab_size=vocab_size, shape=[seq_len],
+                        classes=vocab_size)
+    payload = [dict(parameters=[p for p in model.parameters()], buffers=[b for b in model.buffers()], metadata=data_cfg)]
+    shared = [dict(gradients=[g.detach().to(device) for g in grads], buffers=None,
+                   metadata=dict(num_data_points=1, labels=None, local_hyperparams=None))]
+    return AttrDict(model=model, loss_fn=loss_fn, server_payload=payload, shared_data=shared,
+                    true_user_data=dict(data=tokens, labels=tokens), data_cfg=data_cfg)

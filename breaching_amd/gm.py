@@ -257,7 +257,7 @@ class HipGradientLoss(torch.nn.Module):
             self._plan = plan
         return plan
 
-    def _weights(self, plan):
+    def _weights(self, plan, n_rec):
         return None
 
     def _extra(self):
@@ -270,8 +270,8 @@ class HipGradientLoss(torch.nn.Module):
         plan = self._plan_for(gradient_rec, gradient_data)
         tag_scale, fudge = self._extra()
         kind = _lib.GM_KINDS[self.kind_name]
-        return _GradMatchFunction.apply(plan, kind, float(self.scale), tag_scale, fudge, self._weights(plan),
-                                        *gradient_rec[: plan.n_tensors])
+        return _GradMatchFunction.apply(plan, kind, float(self.scale), tag_scale, fudge,
+                                        self._weights(plan, len(gradient_rec)), *gradient_rec[: plan.n_tensors])
 
     # objectives.py:40-46
     def _single_step_gradient(self, model, candidate, labels):
@@ -372,11 +372,13 @@ class HipEuclideanTag(HipGradientLoss):
     def _extra(self):
         return float(self.tag_scale), 1e-7
 
-    def _weights(self, plan):
+    def _weights(self, plan, n_rec):
+        # The reference sizes the weight ramp by len(gradient_rec) and lets zip() drop the tail (objectives.py:117-125,
+        # :139): with a tied decoder weight the reconstructed list is one longer than the observed one.
         cached = self._weight_cache
-        if cached is not None and cached[0] is plan:
+        if cached is not None and cached[0] is plan and cached[2] == n_rec:
             return cached[1]
-        n = plan.n_tensors
+        n = n_rec
         setup = dict(dtype=torch.float32, device=plan.device)
         if self.scale_scheme == "linear":  # objectives.py:117-118
             weights = torch.arange(n, 0, -1, **setup) / n
@@ -385,8 +387,8 @@ class HipEuclideanTag(HipGradientLoss):
             weights = weights / weights[0]
         else:  # :123-124
             weights = torch.ones(n, **setup)
-        weights = weights.contiguous()
-        self._weight_cache = (plan, weights)
+        weights = weights[: plan.n_tensors].contiguous()
+        self._weight_cache = (plan, weights, n_rec)
         return weights
 
     def __repr__(self):

@@ -341,8 +341,33 @@ def golden_seethrough():
     np.savez_compressed(os.path.join(GOLDEN, "attack_seethrough.npz"), **out)
 
 
+def golden_tag():
+    """BASELINE config 5 family: TAG joint data+label attack (tag-euclidean, AdamW, clipping, warm-up + linear decay) on a
+    tiny random-init BERT masked-LM, run by the reference's OptimizationJointAttacker."""
+    breaching = import_reference(preload_transformers=True)
+    from breaching_amd.cases import build_text_case, parameter_checksum
+
+    torch.set_num_threads(8)
+    out = {}
+    for tag, seed in (("", 3), ("twin_", 4)):
+        case = build_text_case()
+        cfg = _cfg("tag", ["optim.max_iterations=30", "optim.callback=10", "optim.warmup=5"])
+        attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+        torch.manual_seed(seed)  # draws: label template, then per trial data + labels (optimization_with_label_attack.py:42-49, :98-99)
+        rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {})
+        out[f"{tag}history"] = np.asarray(stats["Trial_0_Val"], dtype=np.float64)
+        out[f"{tag}opt_value"] = np.float64(stats["opt_value"])
+        out[f"{tag}tokens"] = rec["data"].numpy()
+        out[f"{tag}labels"] = rec["labels"].numpy()
+        out[f"{tag}raw_embeddings"] = rec["raw_embeddings"].numpy()
+        out[f"{tag}seed"] = np.int64(seed)
+    out["model_checksum"] = np.float64(parameter_checksum(build_text_case().model))
+    out["true_tokens"] = build_text_case().true_user_data["data"].numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "attack_tag.npz"), **out)
+
+
 STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_schedules, convnet=golden_convnet,
-             resnet18=golden_resnet18, seethrough=golden_seethrough)
+             resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag)
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()

@@ -10,7 +10,7 @@ other hardware, can stay within 1e-4 of one particular trajectory for long.  The
   (1) 1e-4 on the loss at the reference's OWN iterates (teacher forcing: our objective + priors evaluated at x_k taken
       from the reference run, early and late in the optimisation),
   (2) 1e-4 on the free-running loss trajectory for as long as the reference's twin runs themselves agree to 3e-5,
-  (3) afterwards, agreement within the reference's own twin envelope (x3, floor 1e-4),
+  (3) afterwards, agreement within the reference's own twin envelope (x3, floor 3e-4),
   (4) PSNR within 0.1 dB (or the twin spread if that is larger).
 Configurations without the sign (soft sign / plain Adam) are not chaotic over the tested horizon and are held to 1e-4
 over the whole trajectory.  The observed gradient is recomputed on CPU so both sides attack the same target.
@@ -72,7 +72,7 @@ def _check_against_golden(prefix, gold, rec, stats, case, crop=None, checksum_re
     # (3) beyond the horizon: inside the envelope spanned by the reference's own twin runs
     envelope = 3.0 * np.abs(twins - hist_ref[None, :]).max(axis=0)
     running = np.maximum.accumulate(envelope)  # a fork, once taken, is never undone
-    allowed = np.maximum(running, LOSS_RTOL * np.abs(hist_ref))
+    allowed = np.maximum(running, 3.0 * LOSS_RTOL * np.abs(hist_ref))  # never tighter than 3e-4 once the reference forks
     excess = np.abs(hist - hist_ref) - allowed
     assert (excess[horizon:] <= 0).all(), f"outside the reference's twin envelope by {excess.max():.3e} at {int(excess.argmax())}"
     twin_opt = gold[f"{prefix}twin_opt_value"]
@@ -265,3 +265,50 @@ def test_invalid_config_strings_raise_value_error():
     att = breaching_amd.prepare_attack(case.model, case.loss_fn, breaching_amd.get_attack_config("invertinggradients", ["init=nope", "optim.max_iterations=1"]), setup)
     with pytest.raises(ValueError):
         att.reconstruct(case.server_payload, case.shared_data, {})
+
+
+def _draw_on_cpu(attacker):
+    """Make the attacker draw its random initialisations from torch's CPU generator (then move them to the GPU), so a
+    seeded run starts exactly where the seeded CPU run of the reference started."""
+    original = attacker._initialize_data
+
+    def cpu_init(shape):
+        device = attacker.setup["device"]
+        attacker.setup["device"] = torch.device("cpu")
+        try:
+            t = original(shape)
+        finally:
+            attacker.setup["device"] = device
+        t = t.detach().to(device).requires_grad_(True)
+        t.grad = torch.zeros_like(t)
+        return t
+
+    attacker._initialize_data = cpu_init
+
+
+def test_tag_joint_attack_on_bert(golden_dir):
+    """BASELINE config 5 family: TAG (tag-euclidean objective with per-tensor weights, AdamW, gradient clipping, warm-up +
+    linear decay) optimising embeddings and labels jointly on a random-init BERT masked-LM; reference =
+    OptimizationJointAttacker run on CPU (oracle/make_golden.py::golden_tag)."""
+    import breaching_amd
+    from breaching_amd.cases import build_text_case, parameter_checksum
+
+    gold = np.load(os.path.join(golden_dir, "attack_tag.npz"))
+    case = build_text_case(device="cuda:0")
+    assert parameter_checksum(case.model) == pytest.approx(float(gold["model_checksum"]), rel=1e-12)
+    cfg = breaching_amd.get_attack_config("tag", ["optim.max_iterations=30", "optim.callback=10", "optim.warmup=5"])
+    attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cuda:0"), dtype=torch.float))
+    assert type(attacker).__name__ == "HipOptimizationJointAttacker"
+    _draw_on_cpu(attacker)
+    torch.manual_seed(int(gold["seed"]))
+    rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {})
+    np.testing.assert_allclose(stats["Trial_0_Val"], gold["history"], rtol=LOSS_RTOL)
+    assert stats["opt_value"] == pytest.approx(float(gold["opt_value"]), rel=LOSS_RTOL)
+    assert set(rec) == {"data", "labels", "raw_embeddings"}
+    np.testing.assert_array_equal(rec["data"].cpu().numpy(), gold["tokens"])
+    np.testing.assert_array_equal(rec["labels"].cpu().numpy(), gold["labels"])
+    np.testing.assert_allclose(rec["raw_embeddings"].cpu().numpy(), gold["raw_embeddings"], rtol=2e-3, atol=2e-4)
+    # labels must be withheld for the joint attack (optimization_with_label_attack.py:54-58)
+    case.shared_data[0]["metadata"]["labels"] = torch.zeros(1, 8, dtype=torch.long, device="cuda:0")
+    with pytest.raises(ValueError, match="Joint optimization"):
+        attacker.reconstruct(case.server_payload, case.shared_data, {})
