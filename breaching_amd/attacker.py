@@ -214,6 +214,8 @@ class HipOptimizationAttacker:
                     buffer.copy_(server_state.to(**self.setup))
             if self.cfg.impl.JIT is not None:
                 raise NotImplementedError("impl.JIT (torch.jit script/trace of the victim model) is not supported.")
+            if fast_eval_bn_enabled(self.cfg):
+                use_affine_eval_batchnorm(new_model)
             models.append(new_model)
         return models
 
@@ -640,6 +642,44 @@ class HipOptimizationAttacker:
 
 
 GRAPH_WARMUP_ITERATIONS = 3
+
+
+class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
+    """BatchNorm2d whose inference-mode forward is written as one broadcast multiply-add.
+
+    Same parameters, buffers, hooks and ``isinstance`` behaviour as ``torch.nn.BatchNorm2d`` (instances are converted by
+    swapping ``__class__``); only the op sequence differs: ``y = x * s + t`` with ``s = w / sqrt(var + eps)``,
+    ``t = b - mean * s``.  PyTorch's double backward of ``F.batch_norm`` in eval mode decomposes into ~25 small kernels
+    per layer per iteration; this formulation needs a handful.  Training-mode batches fall through to the stock path."""
+
+    def forward(self, x):
+        if self.training or self.running_mean is None or self.running_var is None or x.dim() != 4:
+            return super().forward(x)
+        scale = torch.rsqrt(self.running_var + self.eps)
+        if self.weight is not None:
+            scale = scale * self.weight
+        shift = -self.running_mean * scale
+        if self.bias is not None:
+            shift = shift + self.bias
+        return torch.addcmul(shift.view(1, -1, 1, 1), x, scale.view(1, -1, 1, 1))
+
+
+def use_affine_eval_batchnorm(model):
+    """Convert every plain BatchNorm2d of `model` in place (idempotent).  Enabled by cfg.impl.fast_eval_bn / the
+    environment variable BREACH_HIP_FAST_BN=1."""
+    for module in model.modules():
+        if type(module) is torch.nn.BatchNorm2d:
+            module.__class__ = _EvalAffineBatchNorm2d
+    return model
+
+
+def fast_eval_bn_enabled(cfg):
+    import os
+
+    env = os.environ.get("BREACH_HIP_FAST_BN")
+    if env is not None:
+        return env != "0"
+    return bool(_cfg_get(cfg.impl, "fast_eval_bn", False))
 
 
 def graph_replay_enabled(cfg):

@@ -138,3 +138,31 @@ def test_adam_schedule_table_matches_torch_scalars():
         assert table[k, 0] == lr / (1 - 0.9**step)
         assert table[k, 1] == (1 - 0.999**step) ** 0.5
         assert table[k, 2] == 1 - lr * 0.01 and table[k, 3] == lr
+
+
+def test_install_rebinds_the_reference_factory():
+    """`breaching_amd.install()` makes the reference's own `prepare_attack` build our attackers (drop-in seam used by
+    simulate_breach.py:38).  Needs the reference checkout, i.e. runs in the build container only."""
+    from oracle.ref_shim import have_reference, import_reference
+
+    if not have_reference():
+        pytest.skip("reference checkout not present")
+    breaching = import_reference()
+    import breaching_amd
+    from breaching_amd.attacker import HipOptimizationAttacker, HipOptimizationJointAttacker
+    from breaching_amd.cases import build_case
+
+    original = (breaching.attacks.OptimizationBasedAttacker, breaching.attacks.OptimizationJointAttacker)
+    try:
+        breaching_amd.install()
+        assert breaching.attacks.OptimizationBasedAttacker is HipOptimizationAttacker
+        assert breaching.attacks.OptimizationJointAttacker is HipOptimizationJointAttacker
+        case = build_case("convnet", "CIFAR10", 1)
+        cfg = breaching_amd.get_attack_config("invertinggradients")
+        # the reference factory now dispatches to the HIP attacker, which refuses a CPU device instead of falling back
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+        cfg.attack_type = "analytic"  # every other attack type keeps the reference implementation
+        assert type(breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg)).__name__ == "AnalyticAttacker"
+    finally:
+        breaching.attacks.OptimizationBasedAttacker, breaching.attacks.OptimizationJointAttacker = original
