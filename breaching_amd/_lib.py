@@ -119,6 +119,11 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch first: it bundles its own libamdhip64 / libhsa-runtime64.  Loading libbreach_hip.so before torch would pull in
+    # /opt/rocm's runtime instead and leave two HIP runtimes in one process (launches on torch's streams then fail with
+    # hipErrorNoDevice).  With torch loaded, the library's NEEDED libamdhip64.so.* resolves to torch's copy.
+    import torch  # noqa: F401
+
     path = library_path()
     if not os.path.exists(path):
         raise BreachHipError(

@@ -665,8 +665,8 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
 
 
 def use_affine_eval_batchnorm(model):
-    """Convert every plain BatchNorm2d of `model` in place (idempotent).  Enabled by cfg.impl.fast_eval_bn / the
-    environment variable BREACH_HIP_FAST_BN=1."""
+    """Convert every plain BatchNorm2d of `model` in place (idempotent).  On by default; cfg.impl.fast_eval_bn=False or
+    BREACH_HIP_FAST_BN=0 keeps the stock modules."""
     for module in model.modules():
         if type(module) is torch.nn.BatchNorm2d:
             module.__class__ = _EvalAffineBatchNorm2d
@@ -679,7 +679,8 @@ def fast_eval_bn_enabled(cfg):
     env = os.environ.get("BREACH_HIP_FAST_BN")
     if env is not None:
         return env != "0"
-    return bool(_cfg_get(cfg.impl, "fast_eval_bn", False))
+    flag = _cfg_get(cfg.impl, "fast_eval_bn", True)
+    return True if flag is None else bool(flag)
 
 
 def graph_replay_enabled(cfg):

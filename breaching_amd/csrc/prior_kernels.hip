@@ -45,6 +45,17 @@ __device__ __forceinline__ Plane7 sub7(const Plane7& a, const Plane7& b) {
   return Plane7{a.c - b.c, a.s - b.s, a.e - b.e, a.n - b.n, a.ne - b.ne, a.w - b.w, a.sw - b.sw};
 }
 
+// x^e for x > 0 with the exponents the shipped configs use resolved without powf (wave-uniform branches):
+// inner_exp 1 / 2, outer_exp 1 / 0.5 (modern.yaml, legacy.yaml) and the derivative exponents e-1 they induce.
+__device__ __forceinline__ float pow_pos(float x, float e) {
+  if (e == 1.f) return x;
+  if (e == 2.f) return x * x;
+  if (e == 0.5f) return sqrtf(x);
+  if (e == 0.f) return 1.f;
+  if (e == -0.5f) return 1.f / sqrtf(x);
+  return powf(x, e);
+}
+
 // value term and the two partial derivatives of ((|dv|+eps)^p + (|dh|+eps)^p)^q
 template <bool PQ1>
 __device__ __forceinline__ void tv_term(float dv, float dh, float p, float q, float eps, float& f, float& fv, float& fh) {
@@ -54,12 +65,12 @@ __device__ __forceinline__ void tv_term(float dv, float dh, float p, float q, fl
     fv = bh::sgnf(dv);
     fh = bh::sgnf(dh);
   } else {
-    const float ap = powf(a, p), bp = powf(b, p);
+    const float ap = pow_pos(a, p), bp = pow_pos(b, p);
     const float S = ap + bp;
-    f = powf(S, q);
-    const float common = q * powf(S, q - 1.f) * p;
-    fv = common * powf(a, p - 1.f) * bh::sgnf(dv);
-    fh = common * powf(b, p - 1.f) * bh::sgnf(dh);
+    f = pow_pos(S, q);
+    const float common = q * pow_pos(S, q - 1.f) * p;
+    fv = common * pow_pos(a, p - 1.f) * bh::sgnf(dv);
+    fh = common * pow_pos(b, p - 1.f) * bh::sgnf(dh);
   }
 }
 
@@ -159,34 +170,54 @@ __global__ __launch_bounds__(kBlock) void bnstat_sums_kernel(const float* __rest
   float a0 = 0.f, a1 = 0.f;
   double d0 = 0.0, d1 = 0.0;
   const bool vec = (HW & 3) == 0;
-  for (int64_t w = w0; w < w1; ++w) {
-    const int64_t b = w / tiles, t = w - b * tiles;
-    const int64_t start = t * kBnTile;
-    const int64_t len = (HW - start) < kBnTile ? (HW - start) : kBnTile;
-    const float* __restrict__ p = x + ((int64_t)b * C + c) * HW + start;
-    if (vec) {
-      const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
-      const int n4 = (int)(len >> 2);
-      for (int i = threadIdx.x; i < n4; i += kBlock) {
-        const float4 q = p4[i];
-        a0 += (q.x + q.y) + (q.z + q.w);
-        a1 = fmaf(q.x, q.x, a1);
-        a1 = fmaf(q.y, q.y, a1);
-        a1 = fmaf(q.z, q.z, a1);
-        a1 = fmaf(q.w, q.w, a1);
-      }
-    } else {
-      for (int i = threadIdx.x; i < (int)len; i += kBlock) {
-        const float q = p[i];
-        a0 += q;
-        a1 = fmaf(q, q, a1);
+  if (tiles == 1 && HW < 1024) {
+    // small planes (late ResNet stages: 7x7, 14x14): walk (b, hw) as one flat index so all 256 lanes stay busy
+    const int64_t n = (w1 - w0) * HW;
+    int cnt = 0;
+    for (int64_t idx = threadIdx.x; idx < n; idx += kBlock) {
+      const int64_t b = w0 + idx / HW, off = idx % HW;
+      const float q = x[((int64_t)b * C + c) * HW + off];
+      a0 += q;
+      a1 = fmaf(q, q, a1);
+      if (++cnt == 16) {
+        d0 += (double)a0;
+        d1 += (double)a1;
+        a0 = a1 = 0.f;
+        cnt = 0;
       }
     }
-    // spill the fp32 running sums into fp64 once per tile: bounds the fp32 accumulation length to 16 values
     d0 += (double)a0;
     d1 += (double)a1;
-    a0 = 0.f;
-    a1 = 0.f;
+  } else {
+    for (int64_t w = w0; w < w1; ++w) {
+      const int64_t b = w / tiles, t = w - b * tiles;
+      const int64_t start = t * kBnTile;
+      const int64_t len = (HW - start) < kBnTile ? (HW - start) : kBnTile;
+      const float* __restrict__ p = x + ((int64_t)b * C + c) * HW + start;
+      if (vec) {
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+        const int n4 = (int)(len >> 2);
+        for (int i = threadIdx.x; i < n4; i += kBlock) {
+          const float4 q = p4[i];
+          a0 += (q.x + q.y) + (q.z + q.w);
+          a1 = fmaf(q.x, q.x, a1);
+          a1 = fmaf(q.y, q.y, a1);
+          a1 = fmaf(q.z, q.z, a1);
+          a1 = fmaf(q.w, q.w, a1);
+        }
+      } else {
+        for (int i = threadIdx.x; i < (int)len; i += kBlock) {
+          const float q = p[i];
+          a0 += q;
+          a1 = fmaf(q, q, a1);
+        }
+      }
+      // spill the fp32 running sums into fp64 once per tile: bounds the fp32 accumulation length to 16 values
+      d0 += (double)a0;
+      d1 += (double)a1;
+      a0 = 0.f;
+      a1 = 0.f;
+    }
   }
   double v[2] = {d0, d1};
   bh::block_sum<2>(v, lds);
