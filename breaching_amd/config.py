@@ -139,6 +139,68 @@ _ATTACKS = {
             callback=100,
         ),
     ),
+    # breaching/config/attack/modern.yaml
+    "modern": dict(
+        type="invertinggradients",
+        objective=dict(type="cosine-similarity", scale=1.0),
+        init="patterned-4",
+        restarts=dict(num_trials=1, scoring="cosine-similarity"),
+        optim=dict(optimizer="adam", signed="soft", step_size=0.1, boxed=True, max_iterations=24_000,
+                   step_size_decay="cosine-decay", warmup=50, callback=1000),
+        regularization=dict(
+            total_variation=dict(scale=0.1, inner_exp=2, outer_exp=0.5, double_opponents=True),
+            features=dict(scale=0.1),
+            deep_inversion=dict(scale=0.0),
+        ),
+    ),
+    # breaching/config/attack/legacy.yaml
+    "legacy": dict(
+        type="invertinggradients",
+        objective=dict(type="cosine-similarity", scale=1.0),
+        init="zeros",
+        restarts=dict(num_trials=1, scoring="cosine-similarity"),
+        optim=dict(optimizer="adam", signed="soft", step_size=0.1, boxed=True, max_iterations=24_000,
+                   step_size_decay="cosine-decay", callback=1000),
+        regularization=dict(
+            total_variation=dict(scale=0.1, inner_exp=2, outer_exp=0.5, double_opponents=True),
+            features=dict(scale=0.1),
+            deep_inversion=dict(scale=0.00005),
+        ),
+    ),
+    # breaching/config/attack/clsattack.yaml
+    "clsattack": dict(
+        type="invertinggradients",
+        objective=dict(type="cosine-similarity", scale=1.0),
+        init="patterned-4-randn",
+        restarts=dict(num_trials=1, scoring="cosine-similarity"),
+        optim=dict(optimizer="adam", signed="soft", step_size=0.1, boxed=True, max_iterations=24_000,
+                   step_size_decay="cosine-decay", warmup=50, callback=1000),
+        regularization=dict(
+            total_variation=dict(scale=0.2, inner_exp=2, outer_exp=0.5, double_opponents=True),
+            features=dict(scale=0.0),
+            deep_inversion=dict(scale=0.0),
+        ),
+    ),
+    # breaching/config/attack/beyondinfering.yaml (L-BFGS: generic torch.optim loop)
+    "beyondinfering": dict(
+        type="beyond-infering",
+        optim=dict(optimizer="L-BFGS", step_size=1.0, boxed=True, max_iterations=400),
+        regularization=dict(total_variation=dict(scale=0.2352, inner_exp=2, outer_exp=1.25)),
+    ),
+    # breaching/config/attack/wei.yaml (L-BFGS: generic torch.optim loop)
+    "wei": dict(
+        type="beyond-infering",
+        objective=dict(type="euclidean", scale=1.0, task_regularization=1.0),
+        init="patterned-16",
+        optim=dict(optimizer="L-BFGS", step_size=1.0, boxed=True, max_iterations=300),
+    ),
+    # breaching/config/attack/sanitycheck.yaml
+    "sanitycheck": dict(
+        type="sanitycheck",
+        objective=dict(type="cosine-similarity", scale=1.0),
+        optim=dict(optimizer="adam", signed=None, step_size=1, boxed=True, max_iterations=1, step_size_decay="none",
+                   callback=0),
+    ),
     # breaching/config/attack/deepleakage.yaml (L-BFGS joint attack) is served by the generic torch.optim loop.
     "deepleakage": dict(
         type="deep-leakage",

@@ -232,9 +232,96 @@ class HipDeepInversion(torch.nn.Module):
         )
 
 
-# regularizers.py:233-239.  `orthogonality` and `features` are SURVEY section 8(f) "next" rows.
+class _LastLinearInput:
+    """Forward hook keeping the input of a linear layer (regularizers.py:8-20)."""
+
+    def __init__(self, module):
+        self.features = None
+        self.handle = module.register_forward_hook(self)
+
+    def __call__(self, module, inputs, output):
+        self.features = inputs[0]
+
+    def close(self):
+        self.handle.remove()
+
+
+class FeatureRegularization(torch.nn.Module):
+    """regularizers.py:23-60 -- match the input of the last linear layer to the features read off the observed gradient
+    (weight-gradient row / bias-gradient entry of each label).  Plain torch ops: a SURVEY section 8(f) "next" row, kept
+    so that `modern.yaml` / `legacy.yaml` style configs construct and run; it rides the autograd path of the fused loop."""
+
+    def __init__(self, setup, scale=0.1):
+        super().__init__()
+        self.setup = setup
+        self.scale = scale
+        self.refs = []
+
+    def initialize(self, models, shared_data, labels, *args, **kwargs):
+        self.measured_features = []
+        for user_data in shared_data:
+            weights, bias = user_data["gradients"][-2], user_data["gradients"][-1]
+            debiased = weights / bias[:, None]
+            rows = [debiased[label] if bias[label] != 0 else torch.zeros_like(debiased[0]) for label in labels]
+            self.measured_features.append(torch.stack(rows))
+        for ref in self.refs:
+            if ref is not None:
+                ref.close()
+        self.refs = [None for _ in models]
+        for idx, model in enumerate(models):
+            last = None
+            for module in model.modules():
+                if isinstance(module, torch.nn.Linear):
+                    last = module
+            if last is not None:
+                self.refs[idx] = _LastLinearInput(last)
+
+    def release_graph(self):
+        for ref in self.refs:
+            if ref is not None:
+                ref.features = None
+
+    def forward(self, tensor, *args, **kwargs):
+        value = 0
+        for ref, measured in zip(self.refs, self.measured_features):
+            value = value + (ref.features - measured).pow(2).mean()
+        return value * self.scale
+
+    def __repr__(self):
+        return f"Feature space regularization, scale={self.scale}"
+
+
+class OrthogonalityRegularization(torch.nn.Module):
+    """regularizers.py:156-181 -- mean squared pairwise products between batch entries (the reference does not apply
+    `scale` to the value; kept)."""
+
+    def __init__(self, setup, scale=0.1):
+        super().__init__()
+        self.setup = setup
+        self.scale = scale
+
+    def initialize(self, models, *args, **kwargs):
+        pass
+
+    def forward(self, tensor, *args, **kwargs):
+        if tensor.shape[0] == 1:
+            return 0
+        B = tensor.shape[0]
+        products = (tensor.unsqueeze(0) * tensor.unsqueeze(1)).pow(2).view(B, B, -1).mean(dim=2)
+        idx = torch.arange(0, B, device=tensor.device)
+        products[idx, idx] = 0
+        return products.sum()
+
+    def __repr__(self):
+        return f"Input Orthogonality, scale={self.scale}"
+
+
+# regularizers.py:233-239.  TV / norm / DeepInversion run on the HIP kernels; `features` and `orthogonality` are
+# SURVEY section 8(f) "next" rows implemented with plain torch ops for drop-in completeness.
 regularizer_lookup = dict(
     total_variation=HipTotalVariation,
+    orthogonality=OrthogonalityRegularization,
     norm=HipNormRegularization,
     deep_inversion=HipDeepInversion,
+    features=FeatureRegularization,
 )

@@ -69,7 +69,8 @@ def golden_configs():
     """The merged attack configs themselves (pins breaching_amd/config.py against the YAML files)."""
     import json
 
-    out = {name: _cfg(name) for name in ("invertinggradients", "seethroughgradients", "tag", "deepleakage")}
+    out = {name: _cfg(name) for name in ("invertinggradients", "seethroughgradients", "tag", "deepleakage", "modern", "legacy",
+                                       "clsattack", "beyondinfering", "wei", "sanitycheck")}
     data = {name: {k: _data_cfg(name)[k] for k in ("modality", "task", "classes", "shape", "mean", "std")}
             for name in ("CIFAR10", "ImageNet")}
     with open(os.path.join(GOLDEN, "configs.json"), "w") as f:
@@ -300,6 +301,29 @@ def golden_convnet():
     np.savez_compressed(os.path.join(GOLDEN, "attack_convnet.npz"), **out)
 
 
+def golden_variants():
+    """Further configurations through the full loop on ConvNet/CIFAR-10: the `legacy` family (soft sign, double-opponent
+    TV with p=2 q=0.5, feature regulariser, DeepInversion) in the fused loop and the `wei` family (euclidean + task
+    regularisation, L-BFGS) in the generic torch.optim loop."""
+    from breaching_amd.cases import build_case, initial_candidate
+
+    torch.set_num_threads(8)
+    case = build_case("convnet", "CIFAR10", 2)
+    x0 = initial_candidate(case.data_cfg, 2, seed=6)
+    out = {}
+    cfg = _cfg("legacy", ["optim.max_iterations=30", "optim.callback=10", "regularization.deep_inversion.scale=0.001"])
+    rec, stats = _run_reference_attack(cfg, case, x0)
+    out.update({f"legacy_{k}": v for k, v in _attack_record(cfg, case, x0, rec, stats).items()})
+    twins, twin_psnr, twin_opt = _twin_runs(cfg, case, x0, 2)
+    out.update(legacy_twin_history=twins, legacy_twin_psnr=twin_psnr, legacy_twin_opt_value=twin_opt)
+    cfg = _cfg("wei", ["optim.max_iterations=4", "optim.callback=2"])
+    rec, stats = _run_reference_attack(cfg, case, x0)
+    out.update({f"wei_{k}": v for k, v in _attack_record(cfg, case, x0, rec, stats).items()})
+    twins, twin_psnr, twin_opt = _twin_runs(cfg, case, x0, 2)
+    out.update(wei_twin_history=twins, wei_twin_psnr=twin_psnr, wei_twin_opt_value=twin_opt)
+    np.savez_compressed(os.path.join(GOLDEN, "attack_variants.npz"), **out)
+
+
 def golden_resnet18():
     from breaching_amd.cases import build_case, initial_candidate
 
@@ -367,7 +391,8 @@ def golden_tag():
 
 
 STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_schedules, convnet=golden_convnet,
-             resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag)
+             resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
+             variants=golden_variants)
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()

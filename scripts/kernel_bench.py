@@ -111,13 +111,14 @@ for a in acts:
     bufs.append(dict(x=a.contiguous(), B=B_, C=C, HW=HW, sums=torch.empty(C * S * 2, dtype=torch.float64, device=dev),
                      scratch=torch.empty(2 * C, dtype=torch.float64, device=dev), out=torch.empty(1 + 2 * C, device=dev),
                      rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev), grad=torch.empty_like(a)))
-st = _lib.current_stream_handle(dev)
 def d_fwd():
+    st = _lib.current_stream_handle(dev)  # the capture stream while a graph is being recorded
     for b in bufs:
         lib.bh_bnstat_sums(_lib.ptr(b["x"]), b["B"], b["C"], b["HW"], _lib.ptr(b["sums"]), st)
         lib.bh_bnstat_finalize(_lib.ptr(b["sums"]), b["B"], b["C"], b["HW"], _lib.ptr(b["rm"]), _lib.ptr(b["rv"]), _lib.ptr(b["out"]),
                                ctypes_offset(b["out"], 1), _lib.ptr(b["scratch"]), st)
 def d_bwd():
+    st = _lib.current_stream_handle(dev)
     for b in bufs:
         lib.bh_bnstat_bwd(_lib.ptr(b["x"]), b["B"], b["C"], b["HW"], ctypes_offset(b["out"], 1), None, _lib.ptr(b["grad"]), st)
 def graphed(fn):

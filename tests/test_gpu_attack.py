@@ -312,3 +312,33 @@ def test_tag_joint_attack_on_bert(golden_dir):
     case.shared_data[0]["metadata"]["labels"] = torch.zeros(1, 8, dtype=torch.long, device="cuda:0")
     with pytest.raises(ValueError, match="Joint optimization"):
         attacker.reconstruct(case.server_payload, case.shared_data, {})
+
+
+def test_legacy_family_softsign_opponent_tv_features_deepinversion(golden_dir):
+    """`legacy.yaml` family on a 2-image ConvNet case: soft sign, double-opponent TV with p=2 / q=0.5 (general stencil
+    path), feature regulariser (torch ops on the autograd path), DeepInversion prior (kernel D), cosine decay."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case, initial_candidate
+
+    gold = np.load(os.path.join(golden_dir, "attack_variants.npz"))
+    case = build_case("convnet", "CIFAR10", 2, device="cuda:0")
+    x0 = initial_candidate(case.data_cfg, 2, seed=6)
+    cfg = get_attack_config("legacy", ["optim.max_iterations=30", "optim.callback=10", "regularization.deep_inversion.scale=0.001"])
+    rec, stats, attacker = _attack(case, cfg, x0)
+    assert [type(r).__name__ for r in attacker.regularizers] == ["HipTotalVariation", "FeatureRegularization", "HipDeepInversion"]
+    _check_against_golden("legacy_", gold, rec, stats, case)
+
+
+def test_wei_family_lbfgs_generic_loop(golden_dir):
+    """`wei.yaml` family: euclidean objective with task regularisation under L-BFGS -- the generic torch.optim loop with
+    the HIP objective as an autograd node (closure evaluated many times per step)."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case, initial_candidate
+
+    gold = np.load(os.path.join(golden_dir, "attack_variants.npz"))
+    case = build_case("convnet", "CIFAR10", 2, device="cuda:0")
+    x0 = initial_candidate(case.data_cfg, 2, seed=6)
+    cfg = get_attack_config("wei", ["optim.max_iterations=4", "optim.callback=2"])
+    rec, stats, attacker = _attack(case, cfg, x0)
+    assert not attacker._fused_loop_supported()
+    _check_against_golden("wei_", gold, rec, stats, case)
