@@ -290,3 +290,44 @@ def build_text_case(device="cpu", vocab_size=300, seq_len=8, hidden=64, layers=2
                    metadata=dict(num_data_points=1, labels=None, local_hyperparams=None))]
     return AttrDict(model=model, loss_fn=loss_fn, server_payload=payload, shared_data=shared,
                     true_user_data=dict(data=tokens, labels=tokens), data_cfg=data_cfg)
+
+
+def multi_step_update(model, loss_fn, x, labels, steps, data_per_step, lr):
+    """FedAvg user (users.py:336-413, honest case): `steps` plain-SGD steps on consecutive slices of the batch; what
+    is shared is the parameter *difference* p_local - p_server, together with the local hyper-parameters."""
+    from torch.func import functional_call
+
+    names = [n for n, _ in model.named_parameters()]
+    params = [p.detach().clone() for p in model.parameters()]
+    start = [p.clone() for p in params]
+    buffers = dict(model.named_buffers())
+    step_labels, seen = [], 0
+    for _ in range(steps):
+        xs, ys = x[seen : seen + data_per_step], labels[seen : seen + data_per_step]
+        seen = (seen + data_per_step) % x.shape[0]
+        live = [p.requires_grad_(True) for p in params]
+        loss = loss_fn(functional_call(model, ({**dict(zip(names, live)), **buffers},), (xs,)), ys)
+        grads = torch.autograd.grad(loss, live)
+        params = [(p - lr * g).detach() for p, g in zip(live, grads)]
+        step_labels.append(ys)
+    update = [p - s for p, s in zip(params, start)]
+    return [dict(gradients=update, buffers=None,
+                 metadata=dict(num_data_points=x.shape[0], labels=labels,
+                               local_hyperparams=dict(lr=lr, steps=steps, data_per_step=data_per_step, labels=step_labels)))]
+
+
+def build_fedavg_case(device="cpu", num_data_points=4, steps=2, data_per_step=2, lr=0.05, seed_model=0, seed_data=1):
+    data_cfg = get_data_config("CIFAR10")
+    model = build_model("convnet", data_cfg.classes, seed_model)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    x_true, labels = synthetic_user_data(data_cfg, num_data_points, seed_data)
+    shared = multi_step_update(model, loss_fn, x_true, labels, steps, data_per_step, lr)
+    device = torch.device(device)
+    model = model.to(device)
+    for entry in shared:
+        entry["gradients"] = [g.to(device) for g in entry["gradients"]]
+        entry["metadata"]["labels"] = entry["metadata"]["labels"].to(device)
+        entry["metadata"]["local_hyperparams"]["labels"] = [l.to(device) for l in entry["metadata"]["local_hyperparams"]["labels"]]
+    payload = honest_payload(model, data_cfg, public_buffers=True)
+    return AttrDict(model=model, loss_fn=loss_fn, server_payload=payload, shared_data=shared,
+                    true_user_data=dict(data=x_true, labels=labels), data_cfg=data_cfg)

@@ -324,6 +324,21 @@ def golden_variants():
     np.savez_compressed(os.path.join(GOLDEN, "attack_variants.npz"), **out)
 
 
+def golden_fedavg():
+    """FedAvg multi-step objective (objectives.py:48-72): 2 local SGD steps of 2 images each, soft-sign cosine attack."""
+    from breaching_amd.cases import build_fedavg_case, initial_candidate
+
+    torch.set_num_threads(8)
+    case = build_fedavg_case()
+    x0 = initial_candidate(case.data_cfg, 4, seed=6)
+    cfg = _cfg("invertinggradients", ["optim.max_iterations=20", "optim.callback=10", "optim.signed=soft"])
+    rec, stats = _run_reference_attack(cfg, case, x0)
+    out = _attack_record(cfg, case, x0, rec, stats)
+    twins, twin_psnr, twin_opt = _twin_runs(cfg, case, x0, 2)
+    out.update(twin_history=twins, twin_psnr=twin_psnr, twin_opt_value=twin_opt)
+    np.savez_compressed(os.path.join(GOLDEN, "attack_fedavg.npz"), **out)
+
+
 def golden_resnet18():
     from breaching_amd.cases import build_case, initial_candidate
 
@@ -392,7 +407,7 @@ def golden_tag():
 
 STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_schedules, convnet=golden_convnet,
              resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
-             variants=golden_variants)
+             variants=golden_variants, fedavg=golden_fedavg)
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
