@@ -194,7 +194,21 @@ __global__ __launch_bounds__(kBlock) void bnstat_sums_kernel(const float* __rest
       const int64_t start = t * kBnTile;
       const int64_t len = (HW - start) < kBnTile ? (HW - start) : kBnTile;
       const float* __restrict__ p = x + ((int64_t)b * C + c) * HW + start;
-      if (vec) {
+      if (vec && len == kBnTile) {
+        // full tile: four 16-byte loads per thread in flight before the first use
+        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+        float4 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = p4[threadIdx.x + k * kBlock];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          a0 += (q[k].x + q[k].y) + (q[k].z + q[k].w);
+          a1 = fmaf(q[k].x, q[k].x, a1);
+          a1 = fmaf(q[k].y, q[k].y, a1);
+          a1 = fmaf(q[k].z, q[k].z, a1);
+          a1 = fmaf(q[k].w, q[k].w, a1);
+        }
+      } else if (vec) {
         const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
         const int n4 = (int)(len >> 2);
         for (int i = threadIdx.x; i < n4; i += kBlock) {
@@ -327,7 +341,7 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
 int32_t bh_bnstat_slabs(int32_t B, int32_t C, int64_t HW) {
   if (B <= 0 || C <= 0 || HW <= 0) return BH_EINVAL;
   const int64_t items = (int64_t)B * ((HW + kBnTile - 1) / kBnTile);
-  int64_t want = (1024 + C - 1) / C;  // aim for >= 1024 workgroups in total
+  int64_t want = (2048 + C - 1) / C;  // aim for >= 2048 workgroups in total (8 per CU)
   if (want > items) want = items;
   if (want < 1) want = 1;
   if (want > 64) want = 64;
