@@ -63,6 +63,8 @@ def parse_args():
     p.add_argument("--roofline-steps", type=int, default=40, help="eager iterations with per-launch HIP events")
     p.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
     p.add_argument("--channels-last", action="store_true", help="victim model and candidate in NHWC memory format")
+    p.add_argument("--trials-per-gpu", type=int, default=1,
+                   help="independent restarts in flight per GPU on separate streams (BASELINE configs[3]: 32 trials on 8 GPUs = 4)")
     return p.parse_args()
 
 
@@ -114,6 +116,20 @@ def main():
         x0 = x0.contiguous(memory_format=torch.channels_last)
     x0 = x0.requires_grad_(True)
     run = FusedTrial(attacker, [x0], labels, rec_models, case.shared_data)
+    # further restarts on their own streams (same path as HipOptimizationAttacker._run_trial_group)
+    extra = []
+    for j in range(1, args.trials_per_gpu):
+        stream = torch.cuda.Stream(device)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        xj = initial_candidate(case.data_cfg, 1, trial=rank + world * j).to(device).requires_grad_(True)
+        with torch.cuda.stream(stream):
+            extra.append((stream, FusedTrial(attacker, [xj], labels, rec_models, case.shared_data)))
+
+    def step_all():
+        run.step()
+        for stream, other in extra:
+            with torch.cuda.stream(stream):
+                other.step()
     n_elements = sum(p.numel() for p in rec_models[0].parameters())
 
     def barrier():
@@ -123,8 +139,10 @@ def main():
 
     if args.no_graph:
         run.disable_graph()
+        for _, other in extra:
+            other.disable_graph()
     for _ in range(args.warmup):
-        run.step()
+        step_all()
     plan = attacker.objective._plan
     timed_with_events = plan is not None and not args.no_kernel_timing and run.graph is None
     if timed_with_events:
@@ -134,7 +152,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run.step()
+        step_all()
     barrier()
     elapsed = time.perf_counter() - t0
     span_us, span_launches = plan.forward_span_us() if plan is not None else (None, 0)
@@ -231,12 +249,12 @@ def main():
     if rank == 0:
         line = {
             "metric": "attack iters/sec, ResNet-18 ImageNet invertinggradients",
-            "value": round(world * args.steps / elapsed, 3),
+            "value": round(world * args.trials_per_gpu * args.steps / elapsed, 3),
             "unit": "attack iterations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),  # one step of every trial in flight
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -244,7 +262,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.model} (1000 classes, random init) 1x3x224x224, attack=invertinggradients "
                                    "(cosine + TV 0.2, hard-sign Adam, boxed), one trial per GPU",
-                       "gradient_list_elements": n_elements, "trials": world, "parallelism": f"trial-parallel x{world}"},
+                       "gradient_list_elements": n_elements, "trials": world * args.trials_per_gpu,
+                       "trials_in_flight_per_gpu": args.trials_per_gpu, "parallelism": f"trial-parallel x{world}"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "kernels": kernels,

@@ -70,7 +70,6 @@ class GradientMatchPlan:
         raw = torch.frombuffer(bytearray(bytes(self._chunks_host)), dtype=torch.uint8)
         self.chunks_dev = raw.to(self.device)
         self.data_flat = torch.empty(max(self.flat_elems, 4), dtype=torch.float32, device=self.device)
-        self.partials = torch.empty(self.n_chunks * _lib.BH_GM_PARTIAL_STRIDE, dtype=torch.float64, device=self.device)
         self._dummy = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._data_ptr_key = tuple(t.data_ptr() for t in tensors[:4])
         with torch.cuda.device(self.device):
@@ -163,16 +162,18 @@ class GradientMatchPlan:
         """Enqueue forward + finalize; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS]."""
         lib = _lib.load()
         stats = torch.empty(_lib.BH_GM_STAT_WORDS, dtype=torch.float32, device=self.device)
+        # per-call workspace (92 KB for ResNet-18): trials that run concurrently on different streams share this plan
+        partials = torch.empty(self.n_chunks * _lib.BH_GM_PARTIAL_STRIDE, dtype=torch.float64, device=self.device)
         stream = _lib.current_stream_handle(self.device)
         ptrs = self._pointer_array(rec)
         ev0, ev1 = self._timed("fwd")
         _lib.check(
             lib.bh_gm_fwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(self.partials), stream, ev0, ev1),
+                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), stream, ev0, ev1),
             "bh_gm_fwd",
         )
         _lib.check(
-            lib.bh_gm_finalize(kind, _lib.ptr(self.partials), self.n_chunks, float(scale), float(tag_scale), float(fudge),
+            lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_chunks, float(scale), float(tag_scale), float(fudge),
                                _lib.ptr(stats), _lib.ptr(self.span_accum), stream),
             "bh_gm_finalize",
         )

@@ -357,3 +357,20 @@ def test_fedavg_multi_step_objective(golden_dir):
     rec, stats, _ = _attack(case, cfg, x0)
     assert rec["data"].shape == (4, 3, 32, 32)
     _check_against_golden("", gold, rec, stats, case)
+
+
+def test_trials_in_flight_match_sequential_trials():
+    """Running a rank's trials concurrently on separate streams gives every trial exactly the sequential result
+    (non-chaotic soft-sign configuration; each trial starts from its own random draw, identical in both runs)."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case
+
+    over = ["objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft", "optim.max_iterations=10",
+            "restarts.num_trials=3", "restarts.scoring=euclidean", "optim.callback=5"]
+    case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
+    rec_seq, stats_seq, _ = _attack(case, get_attack_config("invertinggradients", over + ["impl.trials_in_flight=1"]), None, seed=3)
+    rec_par, stats_par, _ = _attack(case, get_attack_config("invertinggradients", over + ["impl.trials_in_flight=3"]), None, seed=3)
+    for t in range(3):
+        np.testing.assert_allclose(stats_par[f"Trial_{t}_Val"], stats_seq[f"Trial_{t}_Val"], rtol=1e-5)
+    assert stats_par["opt_value"] == pytest.approx(stats_seq["opt_value"], rel=1e-5)
+    torch.testing.assert_close(rec_par["data"], rec_seq["data"], rtol=1e-4, atol=1e-4)
