@@ -56,7 +56,8 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--cpu-baseline-iters", type=int, default=6, help="timed CPU iterations of the oracle (0 disables)")
+    p.add_argument("--cpu-baseline-iters", type=int, default=80,
+                   help="timed CPU iterations of the oracle, ~10 s of host work (0 disables)")
     p.add_argument("--model", default="resnet18")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in the timed region")
@@ -141,7 +142,11 @@ def main():
         run.disable_graph()
         for _, other in extra:
             other.disable_graph()
-    for _ in range(args.warmup):
+    # hipGraph capture happens after the third eager iteration; keep it out of the timed region even for tiny --warmup
+    from breaching_amd.attacker import GRAPH_WARMUP_ITERATIONS
+
+    warmup_steps = args.warmup if args.no_graph else max(args.warmup, GRAPH_WARMUP_ITERATIONS + 2)
+    for _ in range(warmup_steps):
         step_all()
     plan = attacker.objective._plan
     timed_with_events = plan is not None and not args.no_kernel_timing and run.graph is None
@@ -253,7 +258,7 @@ def main():
             "unit": "attack iterations/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": warmup_steps,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),  # one step of every trial in flight
             "higher_is_better": True,
             "scaling": "weak",
