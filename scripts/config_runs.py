@@ -1,0 +1,60 @@
+"""Run the BASELINE.json configurations through the public API on one MI355X and report wall time / iterations per second.
+
+    python scripts/config_runs.py [--full]        # --full: the real 24 000-iteration ResNet-18 run of configs[1]
+"""
+import argparse, json, logging, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import breaching_amd
+from breaching_amd.cases import build_case, build_text_case, initial_candidate, psnr
+
+parser = argparse.ArgumentParser()
+parser.add_argument("--full", action="store_true")
+parser.add_argument("--only", default=None)
+args = parser.parse_args()
+dev = torch.device("cuda:0")
+setup = dict(device=dev, dtype=torch.float)
+out = {}
+
+
+def run(name, case, cfg, x0=None):
+    attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {}, initial_data=x0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    its = sum(len(v) for k, v in stats.items() if k.startswith("Trial_"))
+    hist = stats["Trial_0_Val"]
+    entry = dict(iterations=its, wall_s=round(dt, 2), iterations_per_s=round(its / dt, 1), first_loss=hist[0], last_loss=hist[-1],
+                 opt_value=stats["opt_value"])
+    if case.data_cfg.modality == "vision":
+        entry["psnr_db"] = round(psnr(rec["data"], case.true_user_data["data"], case.data_cfg), 3)
+    else:
+        entry["token_accuracy"] = float((rec["data"].cpu() == case.true_user_data["data"]).float().mean())
+    out[name] = entry
+    print(name, json.dumps(entry), flush=True)
+
+
+if args.only in (None, "1"):
+    case = build_case("convnet", "CIFAR10", 1, device=dev)
+    run("configs[0] ConvNet CIFAR-10 invertinggradients, 100 its", case,
+        breaching_amd.get_attack_config("invertinggradients", ["optim.max_iterations=100"]), initial_candidate(case.data_cfg, 1, seed=6))
+if args.only in (None, "2"):
+    case = build_case("resnet18", "ImageNet", 1, device=dev, gradient_device=dev)
+    its = 24000 if args.full else 2000
+    run(f"configs[1] ResNet-18 ImageNet invertinggradients, {its} its", case,
+        breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={its}"]), initial_candidate(case.data_cfg, 1))
+if args.only in (None, "3"):
+    case = build_case("resnet50", "ImageNet", 8, device=dev, gradient_device=dev, provide_buffers=True)
+    run("configs[2] ResNet-50 ImageNet batch 8 see-through-gradients (+DeepInversion), 200 its", case,
+        breaching_amd.get_attack_config("seethroughgradients", ["optim.max_iterations=200", "optim.callback=100"]), initial_candidate(case.data_cfg, 8))
+if args.only in (None, "4"):
+    case = build_case("resnet18", "ImageNet", 1, device=dev, gradient_device=dev)
+    run("configs[3] (one GPU's share) ResNet-18 invertinggradients, 4 restarts in flight x 500 its", case,
+        breaching_amd.get_attack_config("invertinggradients", ["optim.max_iterations=500", "restarts.num_trials=4"]))
+if args.only in (None, "5"):
+    case = build_text_case(device=dev, full_size=True, seq_len=32)
+    run("configs[4] BERT-base seq 32 TAG joint attack, 200 its", case,
+        breaching_amd.get_attack_config("tag", ["optim.max_iterations=200", "optim.callback=100"]))
+print(json.dumps(out, indent=1))
