@@ -339,6 +339,26 @@ def golden_fedavg():
     np.savez_compressed(os.path.join(GOLDEN, "attack_fedavg.npz"), **out)
 
 
+def golden_labels():
+    """Label recovery strategies (base_attack.py:305-475) of the reference on a 6-image ConvNet update with repeated labels."""
+    breaching = import_reference()
+    from breaching_amd.cases import build_case
+
+    torch.set_num_threads(8)
+    out = {}
+    for tag, n in (("b6", 6), ("b1", 1)):
+        case = build_case("convnet", "CIFAR10", n, seed_data=5)
+        out[f"{tag}_true"] = case.true_user_data["labels"].numpy()
+        for strategy in ("iDLG", "analytic", "yin", "wainakh-simple", "bias-corrected"):
+            cfg = _cfg("invertinggradients", [f"label_strategy={strategy}"])
+            attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+            shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"], labels=None)) for d in case.shared_data]
+            torch.manual_seed(0)
+            _, labels, _ = attacker.prepare_attack(case.server_payload, shared)
+            out[f"{tag}_{strategy}"] = labels.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "labels.npz"), **out)
+
+
 def golden_resnet18():
     from breaching_amd.cases import build_case, initial_candidate
 
@@ -407,7 +427,7 @@ def golden_tag():
 
 STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_schedules, convnet=golden_convnet,
              resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
-             variants=golden_variants, fedavg=golden_fedavg)
+             variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels)
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
