@@ -395,9 +395,10 @@ def test_label_recovery_strategies_match_reference(golden_dir):
             _, labels, _ = attacker.prepare_attack(case.server_payload, shared)
             want = gold[f"{tag}_{strategy}"]
             assert labels.shape == want.shape and labels.device.type == "cuda"
-            if n == 1 or strategy in ("yin", "wainakh-simple", "bias-corrected"):
+            if n == 1 or strategy in ("wainakh-simple", "bias-corrected"):
                 assert labels.tolist() == want.tolist(), (tag, strategy)
             else:  # deterministic part: every label the strategy can infer is present; the rest is random padding
+                # (iDLG, analytic) or an argsort over exactly tied zeros whose order is device specific (yin)
                 inferred = {7} if strategy == "iDLG" else {4, 6, 7}
                 assert inferred <= set(labels.tolist()), (tag, strategy)
                 assert labels.tolist() == sorted(labels.tolist())
