@@ -718,13 +718,27 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
     def forward(self, x):
         if self.training or self.running_mean is None or self.running_var is None or x.dim() != 4:
             return super().forward(x)
-        scale = torch.rsqrt(self.running_var + self.eps)
+        inv_std, mean_inv = self._frozen_statistics()
         if self.weight is not None:
-            scale = scale * self.weight
-        shift = -self.running_mean * scale
+            scale = self.weight * inv_std
+            shift = -(self.weight * mean_inv)
+        else:
+            scale, shift = inv_std, -mean_inv
         if self.bias is not None:
             shift = shift + self.bias
         return torch.addcmul(shift.view(1, -1, 1, 1), x, scale.view(1, -1, 1, 1))
+
+    def _frozen_statistics(self):
+        """1/sqrt(var+eps) and mean/sqrt(var+eps): constants of the attack (the buffers are fixed once the model is
+        rebuilt from the payload), recomputed only if a buffer is written to."""
+        key = (self.running_mean._version, self.running_var._version, self.running_var.data_ptr(), self.running_var.device)
+        cached = getattr(self, "_frozen", None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                inv_std = torch.rsqrt(self.running_var + self.eps)
+                cached = (key, inv_std, self.running_mean * inv_std)
+            self._frozen = cached
+        return cached[1], cached[2]
 
 
 def use_affine_eval_batchnorm(model):
