@@ -241,10 +241,16 @@ class TokenModel(torch.nn.Module):
         self.model = model
 
     def forward(self, inputs):
-        if inputs.dtype == torch.long:
-            out = self.model(input_ids=inputs)
-        else:
-            out = self.model(inputs_embeds=inputs)
+        # The math backend of scaled_dot_product_attention is plain matmul/softmax ops: it supports the double backward
+        # the attack needs, and (unlike transformers' "eager" mask helper, which builds a device scalar from a host value
+        # on every call) it can be captured into a hipGraph.
+        from torch.nn.attention import SDPBackend, sdpa_kernel
+
+        with sdpa_kernel(SDPBackend.MATH):
+            if inputs.dtype == torch.long:
+                out = self.model(input_ids=inputs)
+            else:
+                out = self.model(inputs_embeds=inputs)
         return out["logits"]
 
 
@@ -262,19 +268,19 @@ class MaskedLMLoss(torch.nn.Module):
 
 
 def build_text_case(device="cpu", vocab_size=300, seq_len=8, hidden=64, layers=2, heads=2, seed_model=0, seed_data=1,
-                    full_size=False):
+                    full_size=False, attention="sdpa"):
     """Random-init BERT masked-LM (tiny by default, bert-base sized with ``full_size``), one sequence of random tokens,
     labels = tokens, user labels withheld (the joint attacker optimises them)."""
     from transformers import BertConfig, BertForMaskedLM
 
     torch.manual_seed(seed_model)
     if full_size:
-        cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation="eager")
+        cfg = BertConfig(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, attn_implementation=attention)
         vocab_size = cfg.vocab_size
     else:
         cfg = BertConfig(vocab_size=vocab_size, hidden_size=hidden, num_hidden_layers=layers, num_attention_heads=heads,
                          intermediate_size=2 * hidden, max_position_embeddings=max(32, seq_len), hidden_dropout_prob=0.0,
-                         attention_probs_dropout_prob=0.0, attn_implementation="eager")
+                         attention_probs_dropout_prob=0.0, attn_implementation=attention)
     model = TokenModel(BertForMaskedLM(cfg))
     model.eval()
     loss_fn = MaskedLMLoss(vocab_size)

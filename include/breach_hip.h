@@ -35,7 +35,9 @@ extern "C" {
 /* Elements handled by one work item of the chunk table.  A tensor of n elements contributes ceil(n/BH_GM_CHUNK)
  * chunks; chunk starts are multiples of BH_GM_CHUNK inside their tensor, hence 16-byte aligned whenever the
  * tensor base is. */
+#ifndef BH_GM_CHUNK
 #define BH_GM_CHUNK 4096
+#endif
 /* Device pointers per launch that travel in the kernel-argument segment.  Longer lists are processed in several
  * launches by the library (transparent to the caller). */
 #define BH_GM_MAX_PTRS 448
