@@ -429,3 +429,21 @@ def test_class_attack_secrets_scatter_the_reconstruction():
     assert float(rec["data"][0].abs().max()) == 0.0 and float(rec["data"][2].abs().max()) == 0.0 and float(rec["data"][1].abs().max()) > 0
     with pytest.raises(TypeError):
         attacker.reconstruct(case.server_payload, case.shared_data, None, initial_data=x0)
+
+
+def test_graph_replay_and_eager_launches_give_the_same_trajectory():
+    """hipGraph replay is an execution-mode change only: same kernels, same order, same results."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case, initial_candidate
+
+    case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
+    x0 = initial_candidate(case.data_cfg, 1, seed=6)
+    over = ["objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft", "optim.max_iterations=15",
+            "restarts.scoring=euclidean", "optim.callback=5"]
+    runs = {}
+    for flag in (True, False):
+        rec, stats, _ = _attack(case, get_attack_config("invertinggradients", over + [f"impl.hip_graph={flag}"]), x0)
+        runs[flag] = (rec["data"].cpu(), np.asarray(stats["Trial_0_Val"]), stats["opt_value"])
+    np.testing.assert_allclose(runs[True][1], runs[False][1], rtol=1e-6)
+    assert runs[True][2] == pytest.approx(runs[False][2], rel=1e-6)
+    torch.testing.assert_close(runs[True][0], runs[False][0], rtol=1e-5, atol=1e-6)
