@@ -359,6 +359,25 @@ def golden_labels():
     np.savez_compressed(os.path.join(GOLDEN, "labels.npz"), **out)
 
 
+def golden_dlg():
+    """Deep Leakage from Gradients (deepleakage.yaml): joint data+label optimisation with L-BFGS on ConvNet -- the generic
+    torch.optim loop of the joint attacker.  Labels withheld; initial data and labels drawn from the seeded CPU generator."""
+    breaching = import_reference()
+    from breaching_amd.cases import build_case, parameter_checksum, psnr
+
+    torch.set_num_threads(8)
+    case = build_case("convnet", "CIFAR10", 1, provide_labels=False)
+    cfg = _cfg("deepleakage", ["optim.max_iterations=3", "optim.callback=1"])
+    attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+    torch.manual_seed(5)
+    rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {})
+    out = dict(history=np.asarray(stats["Trial_0_Val"], dtype=np.float64), opt_value=np.float64(stats["opt_value"]),
+               rec=rec["data"].numpy(), labels=rec["labels"].numpy(), seed=np.int64(5),
+               psnr=np.float64(psnr(rec["data"], case.true_user_data["data"], case.data_cfg)),
+               model_checksum=np.float64(parameter_checksum(case.model)))
+    np.savez_compressed(os.path.join(GOLDEN, "attack_dlg.npz"), **out)
+
+
 def golden_resnet18():
     from breaching_amd.cases import build_case, initial_candidate
 
@@ -427,7 +446,7 @@ def golden_tag():
 
 STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_schedules, convnet=golden_convnet,
              resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
-             variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels)
+             variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg)
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
