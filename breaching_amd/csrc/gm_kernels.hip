@@ -109,34 +109,67 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
   }
 }
 
-// Single workgroup: fixed-order sum of the partial rows, then the objective epilogue.
-__global__ __launch_bounds__(kBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials, int64_t n_rows,
-                                                             float scale, float tag_scale, float fudge,
-                                                             float* __restrict__ stats, double* __restrict__ span_accum) {
-  __shared__ double lds[bh::kWavesPerBlock * 3];
-  __shared__ int span_lds[2 * kBlock];
+// Single workgroup of 1024 threads: fixed-order sum of the partial rows, then the objective epilogue.  Rows are
+// read with four independent row loads in flight per thread (the BERT-base list has 21 k rows); sums go through wave64
+// shuffles and one LDS slot per wave, so the combine order is fixed for a given row count.
+constexpr int kFinalizeBlock = 1024;
+constexpr int kFinalizeWaves = kFinalizeBlock / bh::kWave;
+
+__global__ __launch_bounds__(kFinalizeBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials,
+                                                                     int64_t n_rows, float scale, float tag_scale,
+                                                                     float fudge, float* __restrict__ stats,
+                                                                     double* __restrict__ span_accum) {
+  __shared__ double lds[kFinalizeWaves * 3];
+  __shared__ int span_lds[kFinalizeWaves * 2];
   double v[3] = {0.0, 0.0, 0.0};
   // span of the forward launch in wall-clock ticks: max(end) - min(start), relative to row 0 (wrap safe: 32-bit deltas)
   const unsigned int base_tick =
       (unsigned int)((unsigned long long)__double_as_longlong(partials[BH_GM_PARTIAL_STRIDE - 1]) >> 32);
   int lo = 0x7fffffff, hi = -0x7fffffff;
-  for (int64_t row = threadIdx.x; row < n_rows; row += kBlock) {
-    const double* p = partials + row * BH_GM_PARTIAL_STRIDE;
-    v[0] += p[0];
-    v[1] += p[1];
-    v[2] += p[2];
-    const unsigned long long packed = (unsigned long long)__double_as_longlong(p[3]);
+  auto take = [&](const double4& p) {
+    v[0] += p.x;
+    v[1] += p.y;
+    v[2] += p.z;
+    const unsigned long long packed = (unsigned long long)__double_as_longlong(p.w);
     const int t0 = (int)((unsigned int)(packed >> 32) - base_tick), t1 = (int)((unsigned int)packed - base_tick);
     lo = t0 < lo ? t0 : lo;
     hi = t1 > hi ? t1 : hi;
+  };
+  const double4* __restrict__ rows = reinterpret_cast<const double4*>(partials);
+  int64_t row = threadIdx.x;
+  for (; row + 3 * kFinalizeBlock < n_rows; row += 4 * kFinalizeBlock) {
+    const double4 p0 = rows[row], p1 = rows[row + kFinalizeBlock], p2 = rows[row + 2 * kFinalizeBlock],
+                  p3 = rows[row + 3 * kFinalizeBlock];
+    take(p0);
+    take(p1);
+    take(p2);
+    take(p3);
   }
-  span_lds[threadIdx.x] = lo;
-  span_lds[kBlock + threadIdx.x] = hi;
-  bh::block_sum<3>(v, lds);  // contains the __syncthreads() that also publishes span_lds
+  for (; row < n_rows; row += kFinalizeBlock) take(rows[row]);
+  const int lane = threadIdx.x & (bh::kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = bh::wave_sum(v[k]);
+#pragma unroll
+  for (int off = bh::kWave / 2; off > 0; off >>= 1) {
+    const int olo = __shfl_down(lo, off, bh::kWave), ohi = __shfl_down(hi, off, bh::kWave);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  if (lane == 0) {
+    lds[wave * 3 + 0] = v[0];
+    lds[wave * 3 + 1] = v[1];
+    lds[wave * 3 + 2] = v[2];
+    span_lds[wave * 2 + 0] = lo;
+    span_lds[wave * 2 + 1] = hi;
+  }
+  __syncthreads();
   if (threadIdx.x != 0) return;
-  for (int t = 1; t < kBlock; ++t) {
-    lo = span_lds[t] < lo ? span_lds[t] : lo;
-    hi = span_lds[kBlock + t] > hi ? span_lds[kBlock + t] : hi;
+  for (int w = 1; w < kFinalizeWaves; ++w) {
+    v[0] += lds[w * 3 + 0];
+    v[1] += lds[w * 3 + 1];
+    v[2] += lds[w * 3 + 2];
+    lo = span_lds[w * 2] < lo ? span_lds[w * 2] : lo;
+    hi = span_lds[w * 2 + 1] > hi ? span_lds[w * 2 + 1] : hi;
   }
   const float span_ticks = (float)(hi - lo);
   if (span_accum) {  // running sum / count for bench.py (works under hipGraph replay, no host involvement)
@@ -431,7 +464,8 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
                    float* stats_dev, double* span_accum_dev, void* stream) {
   if (!valid_kind(kind) || partials_dev == nullptr || n_rows <= 0 || stats_dev == nullptr) return BH_EINVAL;
-  hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), kind, partials_dev, n_rows,
+  if ((reinterpret_cast<uintptr_t>(partials_dev) & 31u) != 0) return BH_EINVAL;  // rows are read as 32-byte vectors
+  hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kFinalizeBlock), 0, bh::as_stream(stream), kind, partials_dev, n_rows,
                      scale, tag_scale, fudge, stats_dev, span_accum_dev);
   return bh::launch_status();
 }

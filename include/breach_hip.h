@@ -89,7 +89,7 @@ int bh_gm_build_table(int32_t n_tensors, const int64_t* numel, bh_gm_chunk* chun
 /* Forward partial sums.  `rec_ptrs` is a HOST array of `n_tensors` DEVICE pointers (the tensors returned by
  * autograd this iteration, each contiguous fp32 and 16-byte aligned); `data_flat` is the packed observed gradient;
  * `chunks_dev` the device chunk table; `weights_dev` per-tensor fp32 weights (BH_GM_TAG only, else NULL).
- * `partials_dev` must hold n_chunks rows of BH_GM_PARTIAL_STRIDE doubles; row c belongs to chunk c and is
+ * `partials_dev` (32-byte aligned) must hold n_chunks rows of BH_GM_PARTIAL_STRIDE doubles; row c belongs to chunk c and is
  * overwritten, never accumulated.  `group_chunk_begin` (HOST, bh_gm_num_groups+1 entries, from bh_gm_group_bounds)
  * delimits the chunks of every launch group.
  * reference: objectives.py:89-95, 133-141, 158-166, 183-196, 233-244, 259-273 (the list reductions). */
