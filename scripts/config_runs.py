@@ -51,8 +51,9 @@ if args.only in (None, "3"):
         breaching_amd.get_attack_config("seethroughgradients", ["optim.max_iterations=200", "optim.callback=100"]), initial_candidate(case.data_cfg, 8))
 if args.only in (None, "4"):
     case = build_case("resnet18", "ImageNet", 1, device=dev, gradient_device=dev)
-    run("configs[3] (one GPU's share) ResNet-18 invertinggradients, 4 restarts in flight x 500 its", case,
-        breaching_amd.get_attack_config("invertinggradients", ["optim.max_iterations=500", "restarts.num_trials=4"]))
+    its = 24000 if args.full else 500
+    run(f"configs[3] (one GPU's share) ResNet-18 invertinggradients, 4 restarts in flight x {its} its", case,
+        breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={its}", "restarts.num_trials=4"]))
 if args.only in (None, "5"):
     case = build_text_case(device=dev, full_size=True, seq_len=32)
     run("configs[4] BERT-base seq 32 TAG joint attack, 200 its", case,
