@@ -484,13 +484,16 @@ class HipOptimizationAttacker:
             regularizer.initialize(rec_model, shared_data, labels)
         self.objective.initialize(self.loss_fn, self.cfg.impl, shared_data[0]["metadata"]["local_hyperparams"])
         main = torch.cuda.current_stream(device)
-        streams = {t: torch.cuda.Stream(device) for t in group}
+        # The first trial stays on the caller's stream: HIP multiplexes streams onto 4 hardware queues and the caller's
+        # stream already holds one, so 1 + 3 side streams is the layout that gives every trial in flight its own queue.
+        streams = {t: (main if i == 0 else torch.cuda.Stream(device)) for i, t in enumerate(group)}
         runs = {}
         for t in group:
             candidates = list(init_states[t])
             if initial_data is not None:
                 candidates[0].data = initial_data.data.clone().to(**self.setup).contiguous()
-            streams[t].wait_stream(main)
+            if streams[t] is not main:
+                streams[t].wait_stream(main)
             with torch.cuda.stream(streams[t]):
                 runs[t] = FusedTrial(self, candidates, labels, rec_model, shared_data)
         current_wallclock = time.time()
@@ -523,7 +526,8 @@ class HipOptimizationAttacker:
             with torch.cuda.stream(streams[t]):
                 stats[f"Trial_{t}_Val"].extend(runs[t].loss_history(iterations_run))
                 best = runs[t].best()
-            main.wait_stream(streams[t])
+            if streams[t] is not main:
+                main.wait_stream(streams[t])
             solutions[t] = best[0] if len(best) == 1 else tuple(best)
         return solutions
 
