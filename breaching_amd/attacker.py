@@ -374,50 +374,43 @@ class HipOptimizationAttacker:
 
     # candidate initialisation (base_attack.py:222-285) -----------------------------------------------------------
     def _initialize_data(self, data_shape):
-        init_type = self.cfg.init
-        setup = self.setup
-        data_shape = list(data_shape)
+        """Starting point of a trial, drawn inside the normalised data space (base_attack.py:222-285).
 
-        def _tiled(seed):
-            reps_x = int(torch.as_tensor(data_shape[2] / seed.shape[2]).ceil())
-            reps_y = int(torch.as_tensor(data_shape[3] / seed.shape[3]).ceil())
-            return torch.tile(seed, (1, 1, reps_x, reps_y))[:, :, : data_shape[2], : data_shape[3]].contiguous().clone()
+        Scheme names: ``randn``, ``randn-trunc``, ``rand``, ``zeros``; colour fills ``red|green|blue|dark|light[-true]``;
+        tiled random patches ``[rand|randn]-patterned-K`` and ``[rand-]wei-K`` (K = patch width)."""
+        scheme, setup, shape = self.cfg.init, self.setup, list(data_shape)
 
-        if init_type == "randn":
-            candidate = torch.randn(data_shape, **setup)
-        elif init_type == "randn-trunc":
-            candidate = (torch.randn(data_shape, **setup) * 0.1).clamp(-0.1, 0.1)
-        elif init_type == "rand":
-            candidate = (torch.rand(data_shape, **setup) * 2) - 1.0
-        elif init_type == "zeros":
-            candidate = torch.zeros(data_shape, **setup)
-        elif any(c in init_type for c in ["red", "green", "blue", "dark", "light"]):
-            candidate = torch.zeros(data_shape, **setup)
-            if "light" in init_type:
-                candidate = torch.ones(data_shape, **setup)
-            else:
-                channel = 0 if "red" in init_type else 1 if "green" in init_type else 2
-                candidate[:, channel, :, :] = 1
-            if "-true" in init_type:
+        def uniform_pm1(size):
+            return torch.rand(size, **setup) * 2 - 1.0
+
+        plain = {
+            "randn": lambda: torch.randn(shape, **setup),
+            "randn-trunc": lambda: (torch.randn(shape, **setup) * 0.1).clamp(-0.1, 0.1),
+            "rand": lambda: uniform_pm1(shape),
+            "zeros": lambda: torch.zeros(shape, **setup),
+        }
+        if scheme in plain:
+            candidate = plain[scheme]()
+        elif any(colour in scheme for colour in ("red", "green", "blue", "dark", "light")):
+            if "light" in scheme:
+                candidate = torch.ones(shape, **setup)
+            else:  # "dark" falls through to blue's channel, as in the reference
+                candidate = torch.zeros(shape, **setup)
+                candidate[:, 0 if "red" in scheme else 1 if "green" in scheme else 2, :, :] = 1
+            if "-true" in scheme:  # really RGB, not normalised RGB
                 candidate = (candidate - self.dm) / self.ds
-        elif "patterned" in init_type:
-            width = int("".join(filter(str.isdigit, init_type)))
-            if "randn" in init_type:
-                seed = torch.randn([data_shape[0], 3, width, width], **setup)
-            elif "rand" in init_type:
-                seed = (torch.rand([data_shape[0], 3, width, width], **setup) * 2) - 1
-            else:
-                seed = torch.randn([data_shape[0], 3, width, width], **setup)
-            candidate = _tiled(seed)
-        elif "wei" in init_type:
-            width = int("".join(filter(str.isdigit, init_type)))
-            if "rand" in init_type:
-                seed = (torch.rand([data_shape[0], 3, width, width], **setup) * 2) - 1
-            else:
-                seed = torch.randn([data_shape[0], 3, width, width], **setup)
-            candidate = _tiled(seed)
+        elif "patterned" in scheme or "wei" in scheme:
+            width = int("".join(ch for ch in scheme if ch.isdigit()))
+            patch = [shape[0], 3, width, width]
+            if "patterned" in scheme:  # uniform only when the name says "rand" without the "n"
+                uniform = "rand" in scheme and "randn" not in scheme
+            else:  # wei-K: any "rand" in the name (even "randn") selects the uniform draw -- reference behaviour
+                uniform = "rand" in scheme
+            seed = uniform_pm1(patch) if uniform else torch.randn(patch, **setup)
+            reps = [int(torch.as_tensor(shape[d] / width).ceil()) for d in (2, 3)]
+            candidate = torch.tile(seed, (1, 1, *reps))[:, :, : shape[2], : shape[3]].contiguous().clone()
         else:
-            raise ValueError(f"Unknown initialization scheme {init_type} given.")
+            raise ValueError(f"Unknown initialization scheme {scheme} given.")
         candidate = candidate.contiguous()
         candidate.requires_grad = True
         candidate.grad = torch.zeros_like(candidate)

@@ -166,3 +166,38 @@ def test_install_rebinds_the_reference_factory():
         assert type(breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg)).__name__ == "AnalyticAttacker"
     finally:
         breaching.attacks.OptimizationBasedAttacker, breaching.attacks.OptimizationJointAttacker = original
+
+
+def test_initialisation_schemes_match_reference_bitwise():
+    """Candidate initialisation (base_attack.py:222-285) restated: same seed, same draws, same tensors for every scheme.
+    Runs the method unbound on CPU against the reference's (build container only)."""
+    from oracle.ref_shim import have_reference, import_reference
+
+    if not have_reference():
+        pytest.skip("reference checkout not present")
+    import_reference()
+    from breaching.attacks.base_attack import _BaseAttacker
+
+    from breaching_amd.attacker import HipOptimizationAttacker
+    from breaching_amd.config import AttrDict
+
+    class Holder:
+        pass
+
+    schemes = ["randn", "randn-trunc", "rand", "zeros", "red", "green-true", "blue", "dark", "light-true", "rand-patterned-4",
+               "randn-patterned-8", "patterned-4", "rand-wei-4", "wei-8", "randn-wei-4"]
+    for scheme in schemes:
+        drawn = []
+        for cls in (_BaseAttacker, HipOptimizationAttacker):
+            holder = Holder()
+            holder.cfg = AttrDict(init=scheme)
+            holder.setup = dict(device=torch.device("cpu"), dtype=torch.float32)
+            holder.memory_format = torch.contiguous_format
+            holder.dm = torch.tensor([0.4, 0.5, 0.6])[None, :, None, None]
+            holder.ds = torch.tensor([0.2, 0.3, 0.25])[None, :, None, None]
+            torch.manual_seed(0)
+            drawn.append(cls._initialize_data(holder, [2, 3, 10, 12]).detach())
+        assert torch.equal(drawn[0], drawn[1]), scheme
+    holder.cfg = AttrDict(init="nonsense")
+    with pytest.raises(ValueError):
+        HipOptimizationAttacker._initialize_data(holder, [1, 3, 4, 4])
