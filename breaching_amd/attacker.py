@@ -306,71 +306,89 @@ class HipOptimizationAttacker:
 
     # label recovery (base_attack.py:305-475) ---------------------------------------------------------------------
     def _recover_label_information(self, user_data, server_payload, rec_models):
-        num_data_points = user_data[0]["metadata"]["num_data_points"]
-        num_classes = user_data[0]["gradients"][-1].shape[0]
+        """Labels read off the gradient of the last layer (weight = gradients[-2], bias = gradients[-1]) when the user
+        withholds them.  One small function per strategy; the result is padded with random classes if a strategy infers
+        fewer labels than data points, then sorted (order carries no information)."""
         strategy = self.cfg.label_strategy
-        device = self.setup["device"]
-
         if strategy is None:
             return None
-        elif strategy == "iDLG":  # Zhao et al. 2020: argmin of the row sums of the last weight gradient
-            picks = [torch.argmin(torch.sum(d["gradients"][-2], dim=-1), dim=-1).detach() for d in user_data]
-            labels = torch.stack(picks).unique()
-        elif strategy == "analytic":  # negative bias-gradient entries mark present classes
-            picks = [(d["gradients"][-1] < 0).nonzero() for d in user_data]
-            labels = torch.stack(picks).unique()[:num_data_points]
-        elif strategy == "yin":  # Yin et al. 2021
-            total_min_vals = 0
-            for d in user_data:
-                total_min_vals = total_min_vals + d["gradients"][-2].min(dim=-1)[0]
-            labels = total_min_vals.argsort()[:num_data_points]
-        elif strategy == "wainakh-simple":
-            num_queries = len(user_data)
-            m_impact = 0
-            for d in user_data:
-                g_i = d["gradients"][-2].sum(dim=1)
-                m_query = torch.where(g_i < 0, g_i, torch.zeros_like(g_i)).sum() * (1 + 1 / num_classes) / num_data_points
-                m_impact = m_impact + m_query / num_queries
-            g_i = torch.stack([d["gradients"][-2].sum(dim=1) for d in user_data]).mean(dim=0)
-            label_list = []
-            idx = 0
-            for idx in range(num_classes):
-                if g_i[idx] < 0:
-                    label_list.append(torch.as_tensor(idx, device=device))
-                    g_i[idx] -= m_impact
-            while len(label_list) < num_data_points:
-                selected_idx = g_i.argmin()
-                label_list.append(torch.as_tensor(selected_idx, device=device))
-                g_i[idx] -= m_impact  # sic: the reference decrements the stale loop index (base_attack.py:407)
-            labels = torch.stack(label_list)
-        elif strategy == "bias-corrected":  # the default of the optimisation attacks
-            average_bias = torch.stack([d["gradients"][-1] for d in user_data]).mean(dim=0)
-            valid_classes = (average_bias < 0).nonzero()
-            label_list = [*valid_classes.squeeze(dim=-1)]
-            m_impact = average_bias[valid_classes].sum() / num_data_points
-            average_bias[valid_classes] = average_bias[valid_classes] - m_impact
-            while len(label_list) < num_data_points:
-                selected_idx = average_bias.argmin()
-                label_list.append(selected_idx)
-                average_bias[selected_idx] -= m_impact
-            labels = torch.stack(label_list)
-        elif strategy == "random":
-            labels = torch.randint(0, num_classes, (num_data_points,), device=device)
-        elif strategy == "exhaustive":
-            raise ValueError(
-                f"Exhaustive label searching not implemented; it would need {num_classes ** num_data_points} attacks."
-            )
-        elif strategy in ("wainakh-whitebox", "bias-text"):
+        n = user_data[0]["metadata"]["num_data_points"]
+        num_classes = user_data[0]["gradients"][-1].shape[0]
+        device = self.setup["device"]
+        recover = {
+            "iDLG": self._labels_idlg,
+            "analytic": self._labels_analytic,
+            "yin": self._labels_yin,
+            "wainakh-simple": self._labels_wainakh_simple,
+            "bias-corrected": self._labels_bias_corrected,
+            "random": lambda data, count, classes: torch.randint(0, classes, (count,), device=device),
+        }
+        if strategy == "exhaustive":
+            raise ValueError(f"Exhaustive label searching not implemented; it would need {num_classes ** n} attacks.")
+        if strategy in ("wainakh-whitebox", "bias-text"):
             raise NotImplementedError(f"Label strategy {strategy} is outside the HIP hot-path scope.")
-        else:
+        if strategy not in recover:
             raise ValueError(f"Invalid label recovery strategy {strategy} given.")
-
-        if len(labels) < num_data_points:  # pad with random labels
-            pad = torch.randint(0, num_classes, (num_data_points - len(labels),), device=device)
-            labels = torch.cat([labels, pad])
+        labels = recover[strategy](user_data, n, num_classes)
+        if len(labels) < n:  # pad with random labels
+            labels = torch.cat([labels, torch.randint(0, num_classes, (n - len(labels),), device=device)])
         labels = labels.sort()[0]
         log.info(f"Recovered labels {labels.tolist()} through strategy {strategy}.")
         return labels
+
+    @staticmethod
+    def _labels_idlg(user_data, n, num_classes):
+        # Zhao et al. 2020: the class whose last-layer weight-gradient row sums lowest, per query
+        picks = [torch.argmin(d["gradients"][-2].sum(dim=-1), dim=-1).detach() for d in user_data]
+        return torch.stack(picks).unique()
+
+    @staticmethod
+    def _labels_analytic(user_data, n, num_classes):
+        # classes with a negative bias gradient are present (exact while all labels are distinct)
+        present = [(d["gradients"][-1] < 0).nonzero() for d in user_data]
+        return torch.stack(present).unique()[:n]
+
+    @staticmethod
+    def _labels_yin(user_data, n, num_classes):
+        # Yin et al. 2021: rank classes by the smallest entry of their weight-gradient row (summed over queries)
+        row_minima = 0
+        for d in user_data:
+            row_minima = row_minima + d["gradients"][-2].min(dim=-1)[0]
+        return row_minima.argsort()[:n]
+
+    def _labels_wainakh_simple(self, user_data, n, num_classes):
+        # Wainakh et al.: negative row sums mark present classes; every found label lowers the row sum by an "impact"
+        device = self.setup["device"]
+        impact = 0
+        for d in user_data:
+            row_sums = d["gradients"][-2].sum(dim=1)
+            negative_mass = torch.where(row_sums < 0, row_sums, torch.zeros_like(row_sums)).sum()
+            impact = impact + negative_mass * (1 + 1 / num_classes) / n / len(user_data)
+        row_sums = torch.stack([d["gradients"][-2].sum(dim=1) for d in user_data]).mean(dim=0)
+        found = []
+        cls = 0
+        for cls in range(num_classes):
+            if row_sums[cls] < 0:
+                found.append(torch.as_tensor(cls, device=device))
+                row_sums[cls] -= impact
+        while len(found) < n:
+            found.append(torch.as_tensor(row_sums.argmin(), device=device))
+            row_sums[cls] -= impact  # sic: the reference decrements the stale loop index here (base_attack.py:407)
+        return torch.stack(found)
+
+    @staticmethod
+    def _labels_bias_corrected(user_data, n, num_classes):
+        # the default of the optimisation attacks: analytic recovery, then repeated labels by bias-gradient mass
+        bias = torch.stack([d["gradients"][-1] for d in user_data]).mean(dim=0)
+        present = (bias < 0).nonzero()
+        found = [*present.squeeze(dim=-1)]
+        impact = bias[present].sum() / n
+        bias[present] = bias[present] - impact
+        while len(found) < n:
+            nxt = bias.argmin()
+            found.append(nxt)
+            bias[nxt] -= impact
+        return torch.stack(found)
 
     # candidate initialisation (base_attack.py:222-285) -----------------------------------------------------------
     def _initialize_data(self, data_shape):

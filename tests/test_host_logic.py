@@ -201,3 +201,40 @@ def test_initialisation_schemes_match_reference_bitwise():
     holder.cfg = AttrDict(init="nonsense")
     with pytest.raises(ValueError):
         HipOptimizationAttacker._initialize_data(holder, [1, 3, 4, 4])
+
+
+def test_label_recovery_matches_reference_on_cpu():
+    """Every label strategy, three batch sizes, same seed: identical labels to the reference's
+    `_recover_label_information` (base_attack.py:305-475), random padding included (same CPU draws)."""
+    from oracle.ref_shim import have_reference, import_reference
+
+    if not have_reference():
+        pytest.skip("reference checkout not present")
+    import_reference()
+    from breaching.attacks.base_attack import _BaseAttacker
+
+    from breaching_amd.attacker import HipOptimizationAttacker
+    from breaching_amd.cases import build_case
+    from breaching_amd.config import AttrDict
+
+    class Holder:
+        pass
+
+    helpers = ("_labels_idlg", "_labels_analytic", "_labels_yin", "_labels_wainakh_simple", "_labels_bias_corrected")
+    for n in (6, 1, 3):
+        case = build_case("convnet", "CIFAR10", n, seed_data=5)
+        for strategy in ("iDLG", "analytic", "yin", "wainakh-simple", "bias-corrected", "random"):
+            got = []
+            for cls in (_BaseAttacker, HipOptimizationAttacker):
+                holder = Holder()
+                holder.cfg = AttrDict(label_strategy=strategy)
+                holder.setup = dict(device=torch.device("cpu"), dtype=torch.float32)
+                if cls is HipOptimizationAttacker:
+                    for name in helpers:
+                        fn = getattr(HipOptimizationAttacker, name)
+                        setattr(holder, name, fn.__get__(holder) if name == "_labels_wainakh_simple" else fn)
+                shared = [dict(gradients=[g.clone() for g in d["gradients"]], buffers=None, metadata=dict(d["metadata"], labels=None))
+                          for d in case.shared_data]
+                torch.manual_seed(0)
+                got.append(cls._recover_label_information(holder, shared, case.server_payload, [case.model]))
+            assert torch.equal(got[0], got[1]), (n, strategy)
