@@ -238,3 +238,94 @@ def test_label_recovery_matches_reference_on_cpu():
                 torch.manual_seed(0)
                 got.append(cls._recover_label_information(holder, shared, case.server_payload, [case.model]))
             assert torch.equal(got[0], got[1]), (n, strategy)
+
+
+def _bare_attacker(cls, model, loss_fn, cfg):
+    """An attacker object without running __init__'s device check: the preparation code is device agnostic."""
+    import copy
+
+    obj = object.__new__(cls)
+    obj.cfg = cfg
+    obj.memory_format = torch.contiguous_format
+    obj.setup = dict(device=torch.device("cpu"), dtype=torch.float32)
+    obj.model_template = copy.deepcopy(model)
+    obj.loss_fn = copy.deepcopy(loss_fn)
+    return obj
+
+
+def test_prepare_attack_matches_reference_on_cpu():
+    """`prepare_attack` (base_attack.py:43-74, 169-220, 298-303): model rebuild from payload / user buffers / no buffers,
+    gradient cast and normalisation, box constants, labels -- compared field by field with the reference on CPU."""
+    from oracle.ref_shim import have_reference, import_reference
+
+    if not have_reference():
+        pytest.skip("reference checkout not present")
+    breaching = import_reference()
+    from breaching_amd import get_attack_config
+    from breaching_amd.attacker import HipOptimizationAttacker
+    from breaching_amd.cases import build_case
+
+    for scenario in ("server-buffers", "user-buffers", "no-buffers"):
+        case = build_case("convnet", "CIFAR10", 2, provide_buffers=(scenario == "user-buffers"))
+        if scenario == "no-buffers":
+            case.server_payload[0]["buffers"] = None
+        cfg = get_attack_config("invertinggradients", ["normalize_gradients=True"])
+        ref = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+        ours = _bare_attacker(HipOptimizationAttacker, case.model, case.loss_fn, cfg)
+        results = []
+        for attacker in (ref, ours):
+            shared = [dict(gradients=[g.clone() for g in d["gradients"]], buffers=d["buffers"], metadata=dict(d["metadata"]))
+                      for d in case.shared_data]
+            models, labels, stats = attacker.prepare_attack(case.server_payload, shared)
+            results.append((models, labels, shared, attacker.dm, attacker.ds, attacker.data_shape))
+        (m_r, l_r, s_r, dm_r, ds_r, shape_r), (m_o, l_o, s_o, dm_o, ds_o, shape_o) = results
+        assert torch.equal(l_r, l_o) and torch.equal(dm_r, dm_o) and torch.equal(ds_r, ds_o) and list(shape_r) == list(shape_o)
+        assert m_r[0].training == m_o[0].training == (scenario == "no-buffers")
+        for p, q in zip(m_r[0].parameters(), m_o[0].parameters()):
+            assert torch.equal(p, q)
+        for p, q in zip(m_r[0].buffers(), m_o[0].buffers()):
+            assert torch.equal(p, q)
+        flags_r = [getattr(m, "track_running_stats", None) for m in m_r[0].modules()]
+        flags_o = [getattr(m, "track_running_stats", None) for m in m_o[0].modules()]
+        assert flags_r == flags_o
+        for g, h in zip(s_r[0]["gradients"], s_o[0]["gradients"]):  # cast + normalised in place, like the reference
+            assert torch.equal(g, h)
+        norm = torch.stack([g.pow(2).sum() for g in s_o[0]["gradients"]]).sum().sqrt()
+        assert abs(float(norm) - 1.0) < 1e-5
+
+
+def test_text_preparation_and_token_recovery_match_reference_on_cpu():
+    """Text path of the joint attacker on a tiny BERT: embedding cut-off (base_attack.py:76-122), label-candidate draw
+    (optimization_with_label_attack.py:42-49) and token recovery (base_attack.py:124-167), field by field on CPU."""
+    from oracle.ref_shim import have_reference, import_reference
+
+    if not have_reference():
+        pytest.skip("reference checkout not present")
+    breaching = import_reference(preload_transformers=True)
+    from breaching_amd import get_attack_config
+    from breaching_amd.attacker import HipOptimizationJointAttacker
+    from breaching_amd.cases import build_text_case
+
+    for recovery in ("from-embedding", "from-labels", "from-limited-embedding"):
+        cfg = get_attack_config("tag", [f"token_recovery={recovery}"])
+        out = []
+        for which in ("ref", "ours"):
+            case = build_text_case()
+            if which == "ref":
+                attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+            else:
+                attacker = _bare_attacker(HipOptimizationJointAttacker, case.model, case.loss_fn, cfg)
+            torch.manual_seed(2)
+            models, labels, _ = attacker.prepare_attack(case.server_payload, case.shared_data)
+            gen = torch.Generator().manual_seed(9)
+            embeddings = torch.randn(1, 8, 64, generator=gen)
+            token_labels = torch.randint(0, 300, (1, 8), generator=gen)
+            rec = attacker._postprocess_text_data(dict(data=embeddings.clone(), labels=token_labels.clone()))
+            out.append(dict(labels=labels.detach(), shape=list(attacker.data_shape), n_grads=len(case.shared_data[0]["gradients"]),
+                            n_params=len(list(models[0].parameters())), tokens=rec["data"],
+                            identity=type(models[0].model.bert.embeddings.word_embeddings).__name__))
+        ref, ours = out
+        assert torch.equal(ref["labels"], ours["labels"]) and ref["shape"] == ours["shape"] == [8, 64]
+        assert ref["n_grads"] == ours["n_grads"] == 41 and ref["n_params"] == ours["n_params"] == 42
+        assert ref["identity"] == ours["identity"] == "Identity"
+        assert torch.equal(ref["tokens"], ours["tokens"]), recovery
