@@ -73,7 +73,7 @@ def have_reference():
     return os.path.isdir(os.path.join(REFERENCE_ROOT, "breaching"))
 
 
-def import_reference(preload_transformers=False):
+def import_reference(preload_transformers=True):
     """Return the reference ``breaching`` package, importing it through the stub finder."""
     if not have_reference():
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}; the shim only works in the build container")
@@ -81,9 +81,13 @@ def import_reference(preload_transformers=False):
     if "breaching" in sys.modules:
         return sys.modules["breaching"]
     if preload_transformers:
-        # transformers' image utilities crash against a stubbed torchvision, so import the model classes first.
-        import transformers  # noqa: F401
-        from transformers import BertConfig, BertForMaskedLM  # noqa: F401
+        # transformers' lazy model imports crash against a stubbed torchvision (InterpolationMode.NEAREST_EXACT), so
+        # resolve the model classes the tests use before the stub finder goes in.
+        try:
+            import transformers  # noqa: F401
+            from transformers import BertConfig, BertForMaskedLM  # noqa: F401
+        except ImportError:
+            pass
     if _FINDER not in sys.meta_path:
         sys.meta_path.append(_FINDER)  # appended: real packages always win
     if REFERENCE_ROOT not in sys.path:
