@@ -329,3 +329,45 @@ def test_text_preparation_and_token_recovery_match_reference_on_cpu():
         assert ref["n_grads"] == ours["n_grads"] == 41 and ref["n_params"] == ours["n_params"] == 42
         assert ref["identity"] == ours["identity"] == "Identity"
         assert torch.equal(ref["tokens"], ours["tokens"]), recovery
+
+
+def test_generic_loop_optimizers_and_schedule_match_reference_on_cpu():
+    """`_init_optimizer` (base_attack.py:287-296 -> common.py:5-40) for every optimiser name: same torch.optim class, same
+    hyper-parameters, and the same learning rate before every step as the reference's scheduler produces."""
+    from oracle.ref_shim import have_reference, import_reference
+
+    if not have_reference():
+        pytest.skip("reference checkout not present")
+    import_reference()
+    from breaching.attacks.auxiliaries.common import optimizer_lookup
+
+    from breaching_amd import get_attack_config
+    from breaching_amd.attacker import HipOptimizationAttacker
+
+    for name, sched, warm in (("adam", "step-lr", 0), ("adam-safe", "cosine-decay", 3), ("bert-adam", "linear", 5),
+                              ("momgd", None, 0), ("gd", "step-lr", 2), ("l-bfgs", None, 0)):
+        cfg = get_attack_config("invertinggradients", [f"optim.optimizer={name}", f"optim.step_size_decay={sched or 'null'}",
+                                                       f"optim.warmup={warm}", "optim.max_iterations=40", "optim.step_size=0.3"])
+        ours = object.__new__(HipOptimizationAttacker)
+        ours.cfg = cfg
+        p_ref, p_ours = [torch.zeros(3, requires_grad=True)], [torch.zeros(3, requires_grad=True)]
+        opt_r, sch_r = optimizer_lookup(p_ref, name, 0.3, scheduler=sched, warmup=warm, max_iterations=40)
+        opt_o, sch_o = ours._init_optimizer(p_ours)
+        assert type(opt_r) is type(opt_o)
+        skip = {"params", "lr", "initial_lr"}
+        hyper_r = {k: v for k, v in opt_r.param_groups[0].items() if k not in skip}
+        hyper_o = {k: v for k, v in opt_o.param_groups[0].items() if k not in skip}
+        assert hyper_r == hyper_o
+        for _ in range(40):
+            assert opt_r.param_groups[0]["lr"] == opt_o.param_groups[0]["lr"]
+            if name != "l-bfgs":
+                for p in (p_ref[0], p_ours[0]):
+                    p.grad = torch.ones(3)
+                opt_r.step()
+                opt_o.step()
+            sch_r.step()
+            sch_o.step()
+    bad = object.__new__(HipOptimizationAttacker)
+    bad.cfg = get_attack_config("invertinggradients", ["optim.optimizer=adagrad"])
+    with pytest.raises(ValueError):
+        bad._init_optimizer([torch.zeros(1, requires_grad=True)])
