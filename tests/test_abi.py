@@ -106,3 +106,33 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_header_is_valid_c99(tmp_path):
+    """The boundary is a C ABI: include/breach_hip.h must compile as plain C (no C++-isms, no HIP / torch types)."""
+    import subprocess
+
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "breach_hip.h"\nint main(void) { bh_step_params p; bh_gm_chunk c; (void)p; (void)c; return (int)sizeof(p) * 0; }\n')
+    proc = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-fsyntax-only",
+                           f"-I{os.path.join(ROOT, 'include')}", str(src)], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+
+
+def test_step_params_layout_matches_ctypes(tmp_path):
+    """sizeof / offsetof of bh_step_params as the C compiler sees them == the ctypes mirror in _lib.StepParams."""
+    import subprocess
+
+    from breaching_amd import _lib
+
+    fields = [name for name, _ in _lib.StepParams._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "breach_hip.h"\nint main(void) {\n printf("%zu", sizeof(bh_step_params));\n'
+    prog += "".join(f' printf(" %zu", offsetof(bh_step_params, {f}));\n' for f in fields)
+    prog += " return 0; }\n"
+    src, exe = tmp_path / "layout.c", tmp_path / "layout"
+    src.write_text(prog)
+    subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) == ctypes.sizeof(_lib.StepParams)
+    for name, off in zip(fields, out[1:]):
+        assert int(off) == getattr(_lib.StepParams, name).offset, name
