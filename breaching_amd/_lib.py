@@ -5,17 +5,20 @@ There is deliberately NO fallback: if the shared library is missing or a kernel 
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
 
 from . import build as _build
 
 # ---- constants mirrored from include/breach_hip.h (checked against the library in tests) -------------------------
-BH_ABI_VERSION = 3
+BH_ABI_VERSION = 4
 BH_GM_CHUNK = 4096
 BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
+BH_GM_MAX_ROWS = 2048
 BH_GM_STAT_WORDS = 8
 BH_PRIOR_MAX_GRID = 1024
+BH_BN_MAX_LAYERS = 448
+BH_BN_TILE = 4096
 BH_PRIOR_PARTIAL_STRIDE = 2
 BH_STATE_WORDS = 16
 BH_SCHED_STRIDE = 4
@@ -35,6 +38,21 @@ SIGN_NONE, SIGN_HARD, SIGN_SOFT = 0, 1, 2
 
 class GmChunk(Structure):
     _fields_ = [("flat_off", c_int64), ("tensor_off", c_int64), ("tensor", c_int32), ("len", c_int32)]
+
+
+class GmFused(Structure):
+    _fields_ = [("counter_dev", c_void_p), ("stats_dev", c_void_p), ("span_accum_dev", c_void_p), ("scale", c_float),
+                ("fudge", c_float)]
+
+
+class BnLayer(Structure):
+    _fields_ = [("flat_off", c_int64), ("sums_off", c_int64), ("chan_off", c_int32), ("B", c_int32), ("C", c_int32),
+                ("HW", c_int32), ("S", c_int32), ("narrow", c_int32), ("weight", c_float), ("div_unit_mul", c_uint32),
+                ("div_unit_shr", c_uint32), ("div_c_mul", c_uint32), ("div_c_shr", c_uint32), ("reserved", c_int32)]
+
+
+class BnItem(Structure):
+    _fields_ = [("layer", c_int32), ("a", c_int32), ("b", c_int32), ("c", c_int32)]
 
 
 class StepParams(Structure):
@@ -66,9 +84,11 @@ _PROTOTYPES = {
     "bh_gm_group_bounds": (c_int, [c_int32, POINTER(GmChunk), c_int64, POINTER(c_int32)]),
     "bh_gm_fwd": (
         c_int,
-        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p, c_void_p,
-         c_void_p, c_void_p],
+        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p,
+         POINTER(GmFused), c_void_p, c_void_p, c_void_p],
     ),
+    "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32)]),
+    "bh_gm_set_rows_cap": (c_int32, [c_int32]),
     "bh_gm_finalize": (c_int, [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "bh_wall_clock_khz": (c_int32, []),
     "bh_gm_bwd": (
@@ -81,13 +101,22 @@ _PROTOTYPES = {
         c_int,
         [c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_float, c_int32, c_float, c_float, c_void_p, c_void_p, c_void_p],
     ),
-    "bh_bnstat_slabs": (c_int32, [c_int32, c_int32, c_int64]),
-    "bh_bnstat_sums": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p]),
-    "bh_bnstat_finalize": (
+    "bh_bn_plan_size": (
         c_int,
-        [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64),
+         POINTER(c_int64), POINTER(c_int64)],
     ),
-    "bh_bnstat_bwd": (c_int, [c_void_p, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bh_bn_plan_build": (
+        c_int,
+        [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_float), POINTER(BnLayer), POINTER(BnItem),
+         c_int64, POINTER(BnItem), c_int64],
+    ),
+    "bh_bn_sums": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "bh_bn_finalize": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bh_bn_bwd": (
+        c_int,
+        [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "bh_event_create": (c_int, [POINTER(c_void_p)]),
     "bh_event_destroy": (c_int, [c_void_p]),
     "bh_event_record": (c_int, [c_void_p, c_void_p]),

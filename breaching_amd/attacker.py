@@ -114,19 +114,25 @@ class HipOptimizationAttacker:
         rec_models, labels, stats = self.prepare_attack(server_payload, shared_data)
         num_trials = self.cfg.restarts.num_trials
         shard = trials.TrialShard.current(num_trials)
-        # Draw every trial's starting point in the reference's order so a sharded run uses the same x0 per trial.
         num_points = shared_data[0]["metadata"]["num_data_points"]
-        inits = [self._draw_initial_state(num_points, labels) for _ in range(num_trials)]
+        # Device RNG order.  The reference draws trial t's starting point right before trial t runs, and its Langevin
+        # noise draws (:169) sit between consecutive starting points.  Without noise the order of the starting-point draws
+        # is all that matters, so they are drawn up front (a sharded or concurrent run then starts every trial exactly
+        # where the sequential run does).  With noise on a single rank the reference's interleaving is kept: trials run
+        # one at a time and each draws its start when its turn comes.  Only noise + several ranks deviates (documented).
+        noisy = float(self.cfg.optim.langevin_noise or 0.0) > 0
+        lazy_draws = noisy and shard.world == 1
+        inits = {} if lazy_draws else {t: self._draw_initial_state(num_points, labels) for t in range(num_trials)}
 
         local_scores, local_solutions = {}, {}
         mine = list(shard.local_trials())
-        width = trials_in_flight(self.cfg) if self._fused_loop_supported() else 1
+        width = trials_in_flight(self.cfg) if (self._fused_loop_supported() and not noisy) else 1
         try:
             for start in range(0, len(mine), max(width, 1)):
                 group = mine[start : start + max(width, 1)]
                 if len(group) == 1:
                     solutions = {group[0]: self._run_trial(rec_models, shared_data, labels, stats, group[0], initial_data,
-                                                           dryrun, init_state=inits[group[0]])}
+                                                           dryrun, init_state=inits.get(group[0]))}
                 else:
                     solutions = self._run_trial_group(rec_models, shared_data, labels, stats, group, initial_data, dryrun,
                                                       {t: inits[t] for t in group})
@@ -471,6 +477,7 @@ class HipOptimizationAttacker:
         for regularizer in self.regularizers:
             regularizer.initialize(rec_model, shared_data, labels)
         self.objective.initialize(self.loss_fn, self.cfg.impl, shared_data[0]["metadata"]["local_hyperparams"])
+        self.objective.prepare(rec_model, shared_data)
 
         if init_state is None:
             init_state = self._draw_initial_state(shared_data[0]["metadata"]["num_data_points"], labels)
@@ -494,6 +501,13 @@ class HipOptimizationAttacker:
         for regularizer in self.regularizers:
             regularizer.initialize(rec_model, shared_data, labels)
         self.objective.initialize(self.loss_fn, self.cfg.impl, shared_data[0]["metadata"]["local_hyperparams"])
+        # Shared read-only state is produced on the caller's stream BEFORE the side streams fork from it (they
+        # `wait_stream(main)` below): the packed observed gradients and the frozen statistics of the affine eval-BN layers.
+        self.objective.prepare(rec_model, shared_data)
+        for model in rec_model:
+            for module in model.modules():
+                if isinstance(module, _EvalAffineBatchNorm2d) and not module.training and module.running_var is not None:
+                    module._frozen_statistics()
         main = torch.cuda.current_stream(device)
         # The first trial stays on the caller's stream: HIP multiplexes streams onto 4 hardware queues and the caller's
         # stream already holds one, so 1 + 3 side streams is the layout that gives every trial in flight its own queue.
@@ -846,7 +860,8 @@ class FusedTrial:
             P.beta1, P.beta2, P.eps = hp["betas"][0], hp["betas"][1], hp["eps"]
             P.decoupled_wd = int(hp["decoupled"] and hp["weight_decay"] != 0)
             P.langevin = self.langevin
-            P.grad_clip = float(self.grad_clip) if self.grad_clip is not None else 0.0
+            # negative = no clipping; 0 is a legal threshold (the reference then scales the gradient to ~0, :171-174)
+            P.grad_clip = float(self.grad_clip) if self.grad_clip is not None else -1.0
             P.boxed = int(boxed)
             P.channels, P.plane = 1, max(tensor.numel(), 1)
             if boxed:
@@ -864,6 +879,7 @@ class FusedTrial:
         with torch.cuda.device(device):
             _lib.check(lib.bh_state_reset(_lib.ptr(self.state), _lib.current_stream_handle(device)), "bh_state_reset")
         self.iterations = 0
+        self.tickets = {}  # zeroed device words for kernel A's last-arriver epilogue, one per gradient-match plan
         # hipGraph replay of the whole iteration: the loop is launch-bound (~1.2k kernels per ResNet-18 iteration), and
         # nothing in step() needs the host, so after a few eager iterations the body is captured once and replayed.
         self.graph = None
@@ -913,8 +929,15 @@ class FusedTrial:
             stream = _lib.current_stream_handle(device)
             for tensor in self.candidates:
                 tensor.grad = None
-            total_objective, task_loss = att._autograd_objective(self.candidates, self.labels, self.rec_model,
-                                                                 self.shared_data, self.autograd_regs)
+            scoped = [att.objective] + [reg for reg in self.autograd_regs if hasattr(reg, "ticket_scope")]
+            for owner in scoped:  # this trial's forwards all run on this stream: one re-zeroed ticket word per plan
+                owner.ticket_scope = self.tickets
+            try:
+                total_objective, task_loss = att._autograd_objective(self.candidates, self.labels, self.rec_model,
+                                                                     self.shared_data, self.autograd_regs)
+            finally:
+                for owner in scoped:
+                    owner.ticket_scope = None
             grads = torch.autograd.grad(total_objective, self.candidates, create_graph=False)
             n_reg = 0
             if self.use_prior:

@@ -170,6 +170,13 @@ def initial_candidate(data_cfg, num_data_points, seed=2, trial=0):
     return torch.randn((num_data_points, *data_cfg.shape), generator=gen)
 
 
+def ulp_perturb(x, ulps, gen):
+    """x moved by a random integer in [-ulps, ulps] units in the last place, element-wise (twin starting points: the
+    parity fixtures measure how far the reference's own trajectories spread under such a perturbation)."""
+    step = torch.nextafter(x.abs(), torch.full_like(x, float("inf"))) - x.abs()
+    return x + step * torch.randint(-ulps, ulps + 1, x.shape, generator=gen).to(x.dtype)
+
+
 def honest_payload(model, data_cfg, public_buffers=True):
     """servers.py:138-147 -- references to the live parameters, public buffers for an honest-but-curious server."""
     return [dict(parameters=[p for p in model.parameters()],

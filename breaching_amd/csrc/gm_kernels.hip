@@ -7,9 +7,12 @@
 // Layout: the autograd gradients arrive as T separately allocated tensors whose addresses may change every
 // iteration, so their base pointers travel in the kernel-argument segment (no device table to refresh, no copy,
 // graph-capture friendly).  The observed gradient and the output gradient live in packed flat buffers.  Work is
-// cut into chunks of BH_GM_CHUNK elements that never straddle a tensor; one 256-thread workgroup streams one chunk
-// with 16-byte loads (4 per thread per operand in flight), reduces with wave64 shuffles + LDS and writes one row of
-// fp64 partial sums.  A single-workgroup finalize kernel combines the rows in a fixed order.
+// cut into chunks of BH_GM_CHUNK elements that never straddle a tensor.  The forward launch is a PERSISTENT grid of at
+// most BH_GM_MAX_ROWS 256-thread workgroups (8 per CU = full occupancy on 256 CUs, no tail wave): workgroup w streams
+// chunks w, w+G, w+2G, ... with 16-byte loads (4 per thread per operand in flight), keeps fp32 sums per chunk and fp64
+// sums across chunks, reduces once with wave64 shuffles + LDS and writes ONE row of fp64 partial sums.  The workgroup
+// that finishes last (device-scope ticket) combines the <= 2048 rows in a fixed order and runs the objective epilogue,
+// so forward + finalize is a single launch; a stand-alone finalize kernel does the same for callers that want it.
 //
 // Roofline: HBM-bound, 2*N*4 bytes forward, 3*N*4 bytes backward (N = total elements).  No MFMA: <= 2 flop/byte.
 
@@ -56,126 +59,9 @@ __device__ __forceinline__ void accumulate4(const float4& r, const float4& d, fl
   accumulate<KIND>(r.w, d.w, a0, a1, a2);
 }
 
-template <int KIND>
-__global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
-                                                        const bh_gm_chunk* __restrict__ chunks, int chunk_base,
-                                                        const float* __restrict__ weights, float tag_scale,
-                                                        double* __restrict__ partials) {
-  __shared__ double lds[bh::kWavesPerBlock * 3];
-  const int c = chunk_base + blockIdx.x;
-  const int tid = threadIdx.x;
-  // constant-rate wall clock at block entry (thread 0 only): lets the finalize kernel report the launch's true span
-  const unsigned int tick0 = tid == 0 ? (unsigned int)wall_clock64() : 0u;
-  const bh_gm_chunk ch = chunks[c];
-  const float* __restrict__ r = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
-  const float* __restrict__ d = data_flat + ch.flat_off;
-
-  // two independent accumulator sets keep the fma chains short
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(r);
-  const float4* __restrict__ d4 = reinterpret_cast<const float4*>(d);
-  if (ch.len == BH_GM_CHUNK) {
-    float4 rv[kVecPerThread], dv[kVecPerThread];
-#pragma unroll
-    for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
-#pragma unroll
-    for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
-#pragma unroll
-    for (int k = 0; k < kVecPerThread; k += 2) {
-      accumulate4<KIND>(rv[k], dv[k], a0, a1, a2);
-      if (k + 1 < kVecPerThread) accumulate4<KIND>(rv[k + 1], dv[k + 1], b0, b1, b2);
-    }
-  } else {
-    const int n4 = ch.len >> 2;
-    for (int i = tid; i < n4; i += kBlock) accumulate4<KIND>(r4[i], d4[i], a0, a1, a2);
-    const int tail = ch.len & 3;
-    if (tid < tail) accumulate<KIND>(r[(n4 << 2) + tid], d[(n4 << 2) + tid], b0, b1, b2);
-  }
-  double v[3] = {(double)a0 + (double)b0, (double)a1 + (double)b1, (double)a2 + (double)b2};
-  bh::block_sum<3>(v, lds);
-  if (tid == 0) {
-    double* row = partials + (int64_t)c * BH_GM_PARTIAL_STRIDE;
-    if constexpr (KIND == BH_GM_TAG) {
-      // objectives.py:139-140: (rec-data).pow(2).sum() + tag_scale * weight * (rec-data).abs().sum()
-      const double w = (double)tag_scale * (double)weights[ch.tensor];
-      row[0] = v[0] + w * v[1];
-    } else {
-      row[0] = v[0];
-    }
-    row[1] = v[1];
-    row[2] = v[2];
-    const unsigned long long packed = ((unsigned long long)tick0 << 32) | (unsigned int)wall_clock64();
-    row[3] = __longlong_as_double((long long)packed);
-  }
-}
-
-// Single workgroup of 1024 threads: fixed-order sum of the partial rows, then the objective epilogue.  Rows are
-// read with four independent row loads in flight per thread (the BERT-base list has 21 k rows); sums go through wave64
-// shuffles and one LDS slot per wave, so the combine order is fixed for a given row count.
-constexpr int kFinalizeBlock = 1024;
-constexpr int kFinalizeWaves = kFinalizeBlock / bh::kWave;
-
-__global__ __launch_bounds__(kFinalizeBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials,
-                                                                     int64_t n_rows, float scale, float tag_scale,
-                                                                     float fudge, float* __restrict__ stats,
-                                                                     double* __restrict__ span_accum) {
-  __shared__ double lds[kFinalizeWaves * 3];
-  __shared__ int span_lds[kFinalizeWaves * 2];
-  double v[3] = {0.0, 0.0, 0.0};
-  // span of the forward launch in wall-clock ticks: max(end) - min(start), relative to row 0 (wrap safe: 32-bit deltas)
-  const unsigned int base_tick =
-      (unsigned int)((unsigned long long)__double_as_longlong(partials[BH_GM_PARTIAL_STRIDE - 1]) >> 32);
-  int lo = 0x7fffffff, hi = -0x7fffffff;
-  auto take = [&](const double4& p) {
-    v[0] += p.x;
-    v[1] += p.y;
-    v[2] += p.z;
-    const unsigned long long packed = (unsigned long long)__double_as_longlong(p.w);
-    const int t0 = (int)((unsigned int)(packed >> 32) - base_tick), t1 = (int)((unsigned int)packed - base_tick);
-    lo = t0 < lo ? t0 : lo;
-    hi = t1 > hi ? t1 : hi;
-  };
-  const double4* __restrict__ rows = reinterpret_cast<const double4*>(partials);
-  int64_t row = threadIdx.x;
-  for (; row + 3 * kFinalizeBlock < n_rows; row += 4 * kFinalizeBlock) {
-    const double4 p0 = rows[row], p1 = rows[row + kFinalizeBlock], p2 = rows[row + 2 * kFinalizeBlock],
-                  p3 = rows[row + 3 * kFinalizeBlock];
-    take(p0);
-    take(p1);
-    take(p2);
-    take(p3);
-  }
-  for (; row < n_rows; row += kFinalizeBlock) take(rows[row]);
-  const int lane = threadIdx.x & (bh::kWave - 1), wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) v[k] = bh::wave_sum(v[k]);
-#pragma unroll
-  for (int off = bh::kWave / 2; off > 0; off >>= 1) {
-    const int olo = __shfl_down(lo, off, bh::kWave), ohi = __shfl_down(hi, off, bh::kWave);
-    lo = olo < lo ? olo : lo;
-    hi = ohi > hi ? ohi : hi;
-  }
-  if (lane == 0) {
-    lds[wave * 3 + 0] = v[0];
-    lds[wave * 3 + 1] = v[1];
-    lds[wave * 3 + 2] = v[2];
-    span_lds[wave * 2 + 0] = lo;
-    span_lds[wave * 2 + 1] = hi;
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  for (int w = 1; w < kFinalizeWaves; ++w) {
-    v[0] += lds[w * 3 + 0];
-    v[1] += lds[w * 3 + 1];
-    v[2] += lds[w * 3 + 2];
-    lo = span_lds[w * 2] < lo ? span_lds[w * 2] : lo;
-    hi = span_lds[w * 2 + 1] > hi ? span_lds[w * 2 + 1] : hi;
-  }
-  const float span_ticks = (float)(hi - lo);
-  if (span_accum) {  // running sum / count for bench.py (works under hipGraph replay, no host involvement)
-    span_accum[0] += (double)span_ticks;
-    span_accum[1] += 1.0;
-  }
+// Objective epilogue on the three combined sums (thread 0 of one workgroup).
+__device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float tag_scale, float fudge, float span_ticks,
+                            float* __restrict__ stats) {
   const double s = (double)scale;
   double loss = 0.0, c1 = 0.0, c2 = 0.0;
   if (kind <= BH_GM_ANGULAR) {
@@ -220,6 +106,151 @@ __global__ __launch_bounds__(kFinalizeBlock) void gm_finalize_kernel(int kind, c
   stats[BH_GM_STAT_S2] = (float)v[2];
   stats[BH_GM_STAT_SPAN_TICKS] = span_ticks;
   stats[7] = 0.f;
+}
+
+// Fixed-order combine of `n_rows` partial rows by ONE 256-thread workgroup, then the epilogue: thread t sums rows
+// t, t+256, ... (at most 8 for a single launch group), wave64 shuffles, one LDS slot per wave, thread 0 finishes.  Each
+// row also carries the wall-clock stamps of its workgroup; their envelope is the span of the forward launch.
+__device__ void gm_combine_rows(int kind, const double* partials, int n_rows, float scale, float tag_scale,
+                                float fudge, float* __restrict__ stats, double* __restrict__ span_accum, double* lds,
+                                int* span_lds) {
+  double v[3] = {0.0, 0.0, 0.0};
+  const unsigned int base_tick =
+      (unsigned int)((unsigned long long)__double_as_longlong(partials[BH_GM_PARTIAL_STRIDE - 1]) >> 32);
+  int lo = 0x7fffffff, hi = -0x7fffffff;
+  const double4* rows = reinterpret_cast<const double4*>(partials);  // written by other workgroups: no __restrict__
+  for (int row = threadIdx.x; row < n_rows; row += kBlock) {
+    const double4 p = rows[row];
+    v[0] += p.x;
+    v[1] += p.y;
+    v[2] += p.z;
+    const unsigned long long packed = (unsigned long long)__double_as_longlong(p.w);
+    const int t0 = (int)((unsigned int)(packed >> 32) - base_tick), t1 = (int)((unsigned int)packed - base_tick);
+    lo = t0 < lo ? t0 : lo;  // wrap safe: 32-bit deltas relative to row 0
+    hi = t1 > hi ? t1 : hi;
+  }
+  const int lane = threadIdx.x & (bh::kWave - 1), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v[k] = bh::wave_sum(v[k]);
+#pragma unroll
+  for (int off = bh::kWave / 2; off > 0; off >>= 1) {
+    const int olo = __shfl_down(lo, off, bh::kWave), ohi = __shfl_down(hi, off, bh::kWave);
+    lo = olo < lo ? olo : lo;
+    hi = ohi > hi ? ohi : hi;
+  }
+  if (lane == 0) {
+    lds[wave * 3 + 0] = v[0];
+    lds[wave * 3 + 1] = v[1];
+    lds[wave * 3 + 2] = v[2];
+    span_lds[wave * 2 + 0] = lo;
+    span_lds[wave * 2 + 1] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  for (int w = 1; w < bh::kWavesPerBlock; ++w) {
+    v[0] += lds[w * 3 + 0];
+    v[1] += lds[w * 3 + 1];
+    v[2] += lds[w * 3 + 2];
+    lo = span_lds[w * 2] < lo ? span_lds[w * 2] : lo;
+    hi = span_lds[w * 2 + 1] > hi ? span_lds[w * 2 + 1] : hi;
+  }
+  const float span_ticks = (float)(hi - lo);
+  if (span_accum) {  // running sum / count for bench.py (works under hipGraph replay, no host involvement)
+    span_accum[0] += (double)span_ticks;
+    span_accum[1] += 1.0;
+  }
+  gm_epilogue(kind, v, scale, tag_scale, fudge, span_ticks, stats);
+}
+
+// What the last workgroup of a forward launch needs to finish the objective (all by value in the kernel arguments).
+struct GmFused {
+  unsigned int* counter;       // device ticket, zero before the first launch group; reset by the finisher.  NULL = off
+  unsigned int ticket_target;  // workgroups of ALL launch groups of this forward call
+  int total_rows;              // rows of all launch groups
+  int kind;
+  float scale, fudge;
+  float* stats;
+  double* span_accum;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
+                                                        const bh_gm_chunk* __restrict__ chunks, int chunk_begin,
+                                                        int chunk_end, const float* __restrict__ weights, float tag_scale,
+                                                        double* partials, int row_base, GmFused fused) {
+  __shared__ double lds[bh::kWavesPerBlock * 3];
+  __shared__ int span_lds[bh::kWavesPerBlock * 2];
+  const int tid = threadIdx.x;
+  // constant-rate wall clock at block entry (thread 0 only): lets the combine step report the launch's true span
+  const unsigned int tick0 = tid == 0 ? (unsigned int)wall_clock64() : 0u;
+  double acc[3] = {0.0, 0.0, 0.0};  // per-thread sums across this workgroup's chunks
+  for (int c = chunk_begin + blockIdx.x; c < chunk_end; c += gridDim.x) {
+    const bh_gm_chunk ch = chunks[c];
+    const float* __restrict__ r = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
+    const float* __restrict__ d = data_flat + ch.flat_off;
+    // two independent fp32 accumulator sets keep the fma chains short; at most 16 values each before going to fp64
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    const float4* __restrict__ r4 = reinterpret_cast<const float4*>(r);
+    const float4* __restrict__ d4 = reinterpret_cast<const float4*>(d);
+    if (ch.len == BH_GM_CHUNK) {
+      float4 rv[kVecPerThread], dv[kVecPerThread];
+#pragma unroll
+      for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
+#pragma unroll
+      for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
+#pragma unroll
+      for (int k = 0; k < kVecPerThread; k += 2) {
+        accumulate4<KIND>(rv[k], dv[k], a0, a1, a2);
+        if (k + 1 < kVecPerThread) accumulate4<KIND>(rv[k + 1], dv[k + 1], b0, b1, b2);
+      }
+    } else {
+      const int n4 = ch.len >> 2;
+      for (int i = tid; i < n4; i += kBlock) accumulate4<KIND>(r4[i], d4[i], a0, a1, a2);
+      const int tail = ch.len & 3;
+      if (tid < tail) accumulate<KIND>(r[(n4 << 2) + tid], d[(n4 << 2) + tid], b0, b1, b2);
+    }
+    const double s0 = (double)a0 + (double)b0, s1 = (double)a1 + (double)b1, s2 = (double)a2 + (double)b2;
+    if constexpr (KIND == BH_GM_TAG) {
+      // objectives.py:139-140: (rec-data).pow(2).sum() + tag_scale * weight * (rec-data).abs().sum(), weight per tensor
+      acc[0] += s0 + (double)tag_scale * (double)weights[ch.tensor] * s1;
+    } else {
+      acc[0] += s0;
+    }
+    acc[1] += s1;
+    acc[2] += s2;
+  }
+  bh::block_sum<3>(acc, lds);
+  __shared__ int finisher;
+  if (tid == 0) {
+    double* row = partials + (int64_t)(row_base + blockIdx.x) * BH_GM_PARTIAL_STRIDE;
+    row[0] = acc[0];
+    row[1] = acc[1];
+    row[2] = acc[2];
+    const unsigned long long packed = ((unsigned long long)tick0 << 32) | (unsigned int)wall_clock64();
+    row[3] = __longlong_as_double((long long)packed);
+    int last = 0;
+    if (fused.counter != nullptr) {
+      __threadfence();  // release the row to the other XCDs' L2s before taking a ticket
+      last = atomicAdd(fused.counter, 1u) == fused.ticket_target - 1u;
+    }
+    finisher = last;
+  }
+  if (fused.counter == nullptr) return;
+  __syncthreads();
+  if (!finisher) return;
+  __threadfence();  // acquire: every other workgroup's row is visible now
+  gm_combine_rows(fused.kind, partials, fused.total_rows, fused.scale, tag_scale, fused.fudge, fused.stats,
+                  fused.span_accum, lds, span_lds);
+  if (tid == 0) *fused.counter = 0u;  // ready for the next forward call on this stream
+}
+
+// Stand-alone combine + epilogue (one workgroup): same arithmetic as the fused finisher.
+__global__ __launch_bounds__(kBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials, int n_rows,
+                                                             float scale, float tag_scale, float fudge,
+                                                             float* __restrict__ stats, double* __restrict__ span_accum) {
+  __shared__ double lds[bh::kWavesPerBlock * 3];
+  __shared__ int span_lds[bh::kWavesPerBlock * 2];
+  gm_combine_rows(kind, partials, n_rows, scale, tag_scale, fudge, stats, span_accum, lds, span_lds);
 }
 
 template <int KIND>
@@ -324,14 +355,15 @@ struct LaunchEvents {
 };
 
 template <int KIND>
-void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
-                int n, const float* weights, float tag_scale, double* partials, hipStream_t st, LaunchEvents ev) {
+void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_begin,
+                int chunk_end, int grid, const float* weights, float tag_scale, double* partials, int row_base,
+                const GmFused& fused, hipStream_t st, LaunchEvents ev) {
   if (ev.start || ev.stop)
-    hipExtLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
-                          data_flat, chunks, chunk_base, weights, tag_scale, partials);
+    hipExtLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
+                          data_flat, chunks, chunk_begin, chunk_end, weights, tag_scale, partials, row_base, fused);
   else
-    hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
-                       chunk_base, weights, tag_scale, partials);
+    hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+                       chunk_begin, chunk_end, weights, tag_scale, partials, row_base, fused);
 }
 
 template <int KIND>
@@ -352,6 +384,16 @@ LaunchEvents group_events(void* ev_start, void* ev_stop, bool first, bool last) 
   if (first) ev.start = static_cast<hipEvent_t>(ev_start);
   if (last) ev.stop = static_cast<hipEvent_t>(ev_stop);
   return ev;
+}
+
+// Persistent-grid size for a launch group of n chunks: every workgroup gets the same number of chunks (+-1) and the
+// whole grid is resident at once (<= rows_cap workgroups; 2048 = 8 per CU on 256 CUs).
+int g_rows_cap = BH_GM_MAX_ROWS;
+
+int group_rows(int n_chunks_in_group) {
+  if (n_chunks_in_group <= 0) return 0;
+  const int rounds = (n_chunks_in_group + g_rows_cap - 1) / g_rows_cap;
+  return (n_chunks_in_group + rounds - 1) / rounds;
 }
 
 }  // namespace
@@ -414,58 +456,92 @@ int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
   return 0;
 }
 
+int32_t bh_gm_set_rows_cap(int32_t cap) {
+  if (cap < 1 || cap > BH_GM_MAX_ROWS) return BH_EINVAL;
+  g_rows_cap = cap;
+  return 0;
+}
+
+int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin) {
+  if (n_tensors <= 0 || group_chunk_begin == nullptr) return BH_EINVAL;
+  const int groups = bh_gm_num_groups(n_tensors);
+  int rows = 0;
+  for (int g = 0; g < groups; ++g) rows += group_rows(group_chunk_begin[g + 1] - group_chunk_begin[g]);
+  return rows;
+}
+
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
-              void* ev_stop) {
+              const float* weights_dev, float tag_scale, double* partials_dev, const bh_gm_fused* fused, void* stream,
+              void* ev_start, void* ev_stop) {
   if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
       n_chunks <= 0 || group_chunk_begin == nullptr || partials_dev == nullptr)
     return BH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(partials_dev) & 31u) != 0) return BH_EINVAL;  // rows are read as 32-byte vectors
   if (kind == BH_GM_TAG && weights_dev == nullptr) return BH_EINVAL;
+  if (fused != nullptr && (fused->counter_dev == nullptr || fused->stats_dev == nullptr)) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   const int groups = bh_gm_num_groups(n_tensors);
   for (int g = 0; g < groups; ++g) {  // validate every pointer before anything is enqueued
     GmPtrs probe;
     if (!fill_ptrs(probe, rec_ptrs, n_tensors, g)) return BH_EINVAL;
   }
+  const int total_rows = bh_gm_fwd_rows(n_tensors, group_chunk_begin);
+  GmFused dev_fused{};
+  if (fused != nullptr) {
+    dev_fused.counter = static_cast<unsigned int*>(fused->counter_dev);
+    dev_fused.ticket_target = (unsigned int)total_rows;
+    dev_fused.total_rows = total_rows;
+    dev_fused.kind = kind;
+    dev_fused.scale = fused->scale;
+    dev_fused.fudge = fused->fudge;
+    dev_fused.stats = fused->stats_dev;
+    dev_fused.span_accum = fused->span_accum_dev;
+  }
+  int row_base = 0;
   for (int g = 0; g < groups; ++g) {
-    const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
-    if (n <= 0) continue;
+    const int begin = group_chunk_begin[g], end = group_chunk_begin[g + 1];
+    const int grid = group_rows(end - begin);
+    if (grid <= 0) continue;
     GmPtrs ptrs;
     if (!fill_ptrs(ptrs, rec_ptrs, n_tensors, g)) return BH_EINVAL;
     const int tb = g * BH_GM_MAX_PTRS;
-    const LaunchEvents ev = group_events(ev_start, ev_stop, begin == 0, group_chunk_begin[g + 1] == n_chunks);
+    const LaunchEvents ev = group_events(ev_start, ev_stop, begin == 0, end == n_chunks);
+#define BH_FWD(K) \
+  launch_fwd<K>(ptrs, tb, data_flat, chunks_dev, begin, end, grid, weights_dev, tag_scale, partials_dev, row_base, dev_fused, st, ev)
     switch (kind) {
       case BH_GM_COSINE:
       case BH_GM_COSINE_FAST:
       case BH_GM_ANGULAR:
-        launch_fwd<BH_GM_COSINE>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
+        BH_FWD(BH_GM_COSINE);
         break;
       case BH_GM_COSINE_MASKED:
-        launch_fwd<BH_GM_COSINE_MASKED>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev,
-                                        st, ev);
+        BH_FWD(BH_GM_COSINE_MASKED);
         break;
       case BH_GM_L2:
-        launch_fwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
+        BH_FWD(BH_GM_L2);
         break;
       case BH_GM_L1:
-        launch_fwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
+        BH_FWD(BH_GM_L1);
         break;
       default:
-        launch_fwd<BH_GM_TAG>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, tag_scale, partials_dev, st, ev);
+        BH_FWD(BH_GM_TAG);
         break;
     }
+#undef BH_FWD
     const int rc = bh::launch_status();
     if (rc != 0) return rc;
+    row_base += grid;
   }
   return 0;
 }
 
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
                    float* stats_dev, double* span_accum_dev, void* stream) {
-  if (!valid_kind(kind) || partials_dev == nullptr || n_rows <= 0 || stats_dev == nullptr) return BH_EINVAL;
+  if (!valid_kind(kind) || partials_dev == nullptr || n_rows <= 0 || n_rows > INT32_MAX || stats_dev == nullptr)
+    return BH_EINVAL;
   if ((reinterpret_cast<uintptr_t>(partials_dev) & 31u) != 0) return BH_EINVAL;  // rows are read as 32-byte vectors
-  hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kFinalizeBlock), 0, bh::as_stream(stream), kind, partials_dev, n_rows,
+  hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), kind, partials_dev, (int)n_rows,
                      scale, tag_scale, fudge, stats_dev, span_accum_dev);
   return bh::launch_status();
 }

@@ -4,8 +4,8 @@
 //      reference: breaching/attacks/auxiliaries/regularizers.py:103-153 (grouped 3x3 conv of forward differences with
 //      zero padding, abs + eps, inner / outer exponents, mean) and :184-200 (scale / p * mean(x^p)).  The reference
 //      pays a grouped MIOpen conv + ~5 elementwise launches + their autograd backward on a 0.6-4.8 MB tensor.
-// D -- DeepInversion batch-norm statistics prior: per-channel mean / biased variance of a BN input compared with the
-//      running statistics.  Restated from the mathematical definition only (the reference file
+// D -- DeepInversion batch-norm statistics prior: per-channel mean / biased variance of every BN input of the model
+//      compared with the running statistics, all layers per launch.  Restated from the mathematical definition only (the reference file
 //      auxiliaries/deepinversion.py is NVIDIA-NC licensed; no code was taken from it):
 //          r = || running_var - var ||_2 + || running_mean - mean ||_2            (deepinversion.py:93-101)
 //      and d r / d x[b,c,hw] = A_c + B_c * x[b,c,hw].
@@ -154,52 +154,64 @@ __global__ __launch_bounds__(kBlock) void tv_norm_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Kernel D
+// Kernel D: all BatchNorm inputs of a model in ONE launch per stage
 // ---------------------------------------------------------------------------------------------------------------
+//
+// The reference hook fires once per BN layer (53 for ResNet-50) and spends ~10 launches each; a per-layer HIP kernel is
+// still 53 x 3 launches whose 2-6 us floor dominates (round 1: 0.58 TB/s effective).  Here the layers travel as a
+// pointer list in the kernel arguments plus a device table of layer descriptors, and the three stages are one launch
+// each: sums over every (layer, channel, slab), finalize with one workgroup per layer (the last one to finish adds up
+// the layers in a fixed order), and one elementwise backward over every layer writing a packed gradient buffer.
 
-constexpr int64_t kBnTile = 4096;  // elements of one (b, c) plane handled per inner step
+struct BnPtrs {
+  const float* p[BH_BN_MAX_LAYERS];
+};
 
-// grid = (C, S).  Workgroup (c, s) sums slab s of channel c: the (b, tile) work items [w0, w1) of that channel.
-__global__ __launch_bounds__(kBlock) void bnstat_sums_kernel(const float* __restrict__ x, int B, int C, int64_t HW, int S,
-                                                             double* __restrict__ sums) {
+// n / d and n % d for 0 <= n < 2^31 with a host-computed multiplier (d = 1: mul = shr = 0)
+__device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, uint32_t mul, uint32_t shr, uint32_t& q, uint32_t& r) {
+  q = d != 1u ? (__umulhi(n, mul) >> shr) : n;
+  r = n - q * d;
+}
+
+// One workgroup per forward item (layer, channel, slab).  The B planes of a channel are treated as one virtual array of
+// B * HW elements; slab s owns an even share of it.  Wide layers: the whole workgroup walks the share; narrow layers
+// (B * HW small, late ResNet stages): one wavefront per channel, four channels per workgroup.  Each thread keeps fp32
+// sums over at most 16 values before spilling into fp64.
+__global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
+                                                         const bh_bn_item* __restrict__ items,
+                                                         double* __restrict__ sums) {
   __shared__ double lds[bh::kWavesPerBlock * 2];
-  const int c = blockIdx.x, s = blockIdx.y;
-  const int64_t tiles = (HW + kBnTile - 1) / kBnTile;
-  const int64_t items = (int64_t)B * tiles;
-  const int64_t w0 = items * s / S, w1 = items * (s + 1) / S;
-  float a0 = 0.f, a1 = 0.f;
+  const bh_bn_item it = items[blockIdx.x];
+  const bh_bn_layer L = layers[it.layer];
+  const float* __restrict__ x = ptrs.p[it.layer];
+  const int tid = threadIdx.x;
+  const bool narrow = L.narrow != 0;
+  const int lanes = narrow ? bh::kWave : kBlock;
+  const int lane = narrow ? (tid & (bh::kWave - 1)) : tid;
+  const int c = narrow ? it.a + (tid >> 6) : it.a;
+  const bool active = c < L.C;
+  const bool vec = (L.HW & 3) == 0;
+  const uint32_t unit = vec ? (uint32_t)(L.HW >> 2) : (uint32_t)L.HW;  // float4s (or floats) per plane
+  const uint32_t total = (uint32_t)L.B * unit;
+  const uint32_t v0 = (uint32_t)((uint64_t)total * (uint32_t)it.b / (uint32_t)L.S);
+  const uint32_t v1 = (uint32_t)((uint64_t)total * ((uint32_t)it.b + 1u) / (uint32_t)L.S);
   double d0 = 0.0, d1 = 0.0;
-  const bool vec = (HW & 3) == 0;
-  if (tiles == 1 && HW < 1024) {
-    // small planes (late ResNet stages: 7x7, 14x14): walk (b, hw) as one flat index so all 256 lanes stay busy
-    const int64_t n = (w1 - w0) * HW;
-    int cnt = 0;
-    for (int64_t idx = threadIdx.x; idx < n; idx += kBlock) {
-      const int64_t b = w0 + idx / HW, off = idx % HW;
-      const float q = x[((int64_t)b * C + c) * HW + off];
-      a0 += q;
-      a1 = fmaf(q, q, a1);
-      if (++cnt == 16) {
-        d0 += (double)a0;
-        d1 += (double)a1;
-        a0 = a1 = 0.f;
-        cnt = 0;
-      }
-    }
-    d0 += (double)a0;
-    d1 += (double)a1;
-  } else {
-    for (int64_t w = w0; w < w1; ++w) {
-      const int64_t b = w / tiles, t = w - b * tiles;
-      const int64_t start = t * kBnTile;
-      const int64_t len = (HW - start) < kBnTile ? (HW - start) : kBnTile;
-      const float* __restrict__ p = x + ((int64_t)b * C + c) * HW + start;
-      if (vec && len == kBnTile) {
-        // full tile: four 16-byte loads per thread in flight before the first use
-        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+  if (active) {
+    if (vec) {
+      const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+      const uint32_t cstride = (uint32_t)L.C * unit;  // float4s between consecutive planes of one channel
+      const uint32_t cbase = (uint32_t)c * unit;
+      uint32_t v = v0 + (uint32_t)lane;
+      // four independent 16-byte loads in flight per thread
+      for (; v + 3u * lanes < v1; v += 4u * lanes) {
         float4 q[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) q[k] = p4[threadIdx.x + k * kBlock];
+        for (int k = 0; k < 4; ++k) {
+          uint32_t b, j;
+          fast_divmod(v + (uint32_t)(k * lanes), unit, L.div_unit_mul, L.div_unit_shr, b, j);
+          q[k] = x4[(size_t)b * cstride + cbase + j];
+        }
+        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           a0 += (q[k].x + q[k].y) + (q[k].z + q[k].w);
@@ -208,61 +220,94 @@ __global__ __launch_bounds__(kBlock) void bnstat_sums_kernel(const float* __rest
           a1 = fmaf(q[k].z, q[k].z, a1);
           a1 = fmaf(q[k].w, q[k].w, a1);
         }
-      } else if (vec) {
-        const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
-        const int n4 = (int)(len >> 2);
-        for (int i = threadIdx.x; i < n4; i += kBlock) {
-          const float4 q = p4[i];
-          a0 += (q.x + q.y) + (q.z + q.w);
-          a1 = fmaf(q.x, q.x, a1);
-          a1 = fmaf(q.y, q.y, a1);
-          a1 = fmaf(q.z, q.z, a1);
-          a1 = fmaf(q.w, q.w, a1);
-        }
-      } else {
-        for (int i = threadIdx.x; i < (int)len; i += kBlock) {
-          const float q = p[i];
-          a0 += q;
-          a1 = fmaf(q, q, a1);
-        }
+        d0 += (double)a0;
+        d1 += (double)a1;
       }
-      // spill the fp32 running sums into fp64 once per tile: bounds the fp32 accumulation length to 16 values
+      float a0 = 0.f, a1 = 0.f;
+      for (; v < v1; v += lanes) {
+        uint32_t b, j;
+        fast_divmod(v, unit, L.div_unit_mul, L.div_unit_shr, b, j);
+        const float4 q = x4[(size_t)b * cstride + cbase + j];
+        a0 += (q.x + q.y) + (q.z + q.w);
+        a1 = fmaf(q.x, q.x, a1);
+        a1 = fmaf(q.y, q.y, a1);
+        a1 = fmaf(q.z, q.z, a1);
+        a1 = fmaf(q.w, q.w, a1);
+      }
       d0 += (double)a0;
       d1 += (double)a1;
-      a0 = 0.f;
-      a1 = 0.f;
+    } else {
+      const size_t cstride = (size_t)L.C * unit;
+      const size_t cbase = (size_t)c * unit;
+      float a0 = 0.f, a1 = 0.f;
+      int cnt = 0;
+      for (uint32_t v = v0 + (uint32_t)lane; v < v1; v += lanes) {
+        uint32_t b, j;
+        fast_divmod(v, unit, L.div_unit_mul, L.div_unit_shr, b, j);
+        const float q = x[(size_t)b * cstride + cbase + j];
+        a0 += q;
+        a1 = fmaf(q, q, a1);
+        if (++cnt == 16) {
+          d0 += (double)a0;
+          d1 += (double)a1;
+          a0 = a1 = 0.f;
+          cnt = 0;
+        }
+      }
+      d0 += (double)a0;
+      d1 += (double)a1;
     }
   }
-  double v[2] = {d0, d1};
-  bh::block_sum<2>(v, lds);
-  if (threadIdx.x == 0) {
-    sums[((int64_t)c * S + s) * 2 + 0] = v[0];
-    sums[((int64_t)c * S + s) * 2 + 1] = v[1];
+  if (narrow) {
+    d0 = bh::wave_sum(d0);
+    d1 = bh::wave_sum(d1);
+    if (lane == 0 && active) {
+      double* out = sums + 2 * (L.sums_off + (int64_t)c * L.S + it.b);
+      out[0] = d0;
+      out[1] = d1;
+    }
+  } else {
+    double v[2] = {d0, d1};
+    bh::block_sum<2>(v, lds);
+    if (tid == 0) {
+      double* out = sums + 2 * (L.sums_off + (int64_t)c * L.S + it.b);
+      out[0] = v[0];
+      out[1] = v[1];
+    }
   }
 }
 
-// Single workgroup; thread t owns channels t, t+256, ...
-__global__ __launch_bounds__(kBlock) void bnstat_finalize_kernel(const double* __restrict__ sums, int B, int C, int64_t HW,
-                                                                 int S, const float* __restrict__ running_mean,
-                                                                 const float* __restrict__ running_var,
-                                                                 float* __restrict__ value, float* __restrict__ coef,
-                                                                 double* __restrict__ scratch /* [2*C] mean,var */) {
+// One workgroup per layer: per-channel mean / biased variance from the slab sums, the two norms of the differences to
+// the running statistics, the layer's weighted statistic and the backward coefficients
+//   d (w * r) / d x[b,c,hw] = A_c + B_c * x[b,c,hw].
+// The workgroup that finishes last adds the layers up in index order (fixed order => reproducible) into total[0].
+__global__ __launch_bounds__(kBlock) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
+                                                             const double* __restrict__ sums,
+                                                             const float* __restrict__ running_mean,
+                                                             const float* __restrict__ running_var,
+                                                             float* __restrict__ coef, double* layer_values,
+                                                             float* __restrict__ total, unsigned int* counter) {
   __shared__ double lds[bh::kWavesPerBlock * 2];
   __shared__ double norms[2];
-  const double n = (double)B * (double)HW;
-  double v[2] = {0.0, 0.0};  // sum (rv - var)^2, sum (rm - mean)^2
-  for (int c = threadIdx.x; c < C; c += kBlock) {
+  __shared__ int finisher;
+  const bh_bn_layer L = layers[blockIdx.x];
+  const double n = (double)L.B * (double)L.HW;
+  auto channel_stats = [&](int c, double& mean, double& var) {
     double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < S; ++s) {
-      s0 += sums[((int64_t)c * S + s) * 2 + 0];
-      s1 += sums[((int64_t)c * S + s) * 2 + 1];
+    const double* row = sums + 2 * (L.sums_off + (int64_t)c * L.S);
+    for (int s = 0; s < L.S; ++s) {
+      s0 += row[2 * s];
+      s1 += row[2 * s + 1];
     }
-    const double mean = s0 / n;
-    double var = s1 / n - mean * mean;
+    mean = s0 / n;
+    var = s1 / n - mean * mean;
     var = var < 0.0 ? 0.0 : var;
-    scratch[2 * c] = mean;
-    scratch[2 * c + 1] = var;
-    const double dvv = (double)running_var[c] - var, dm = (double)running_mean[c] - mean;
+  };
+  double v[2] = {0.0, 0.0};  // sum (rv - var)^2, sum (rm - mean)^2
+  for (int c = threadIdx.x; c < L.C; c += kBlock) {
+    double mean, var;
+    channel_stats(c, mean, var);
+    const double dvv = (double)running_var[L.chan_off + c] - var, dm = (double)running_mean[L.chan_off + c] - mean;
     v[0] += dvv * dvv;
     v[1] += dm * dm;
   }
@@ -270,41 +315,118 @@ __global__ __launch_bounds__(kBlock) void bnstat_finalize_kernel(const double* _
   if (threadIdx.x == 0) {
     norms[0] = sqrt(v[0]);
     norms[1] = sqrt(v[1]);
-    value[0] = (float)(norms[0] + norms[1]);
   }
   __syncthreads();
-  const double nv = norms[0], nm = norms[1];
-  for (int c = threadIdx.x; c < C; c += kBlock) {
-    const double mean = scratch[2 * c], var = scratch[2 * c + 1];
-    const double pv = nv > 0.0 ? -((double)running_var[c] - var) / nv : 0.0;   // d r / d var_c
-    const double pm = nm > 0.0 ? -((double)running_mean[c] - mean) / nm : 0.0; // d r / d mean_c
-    coef[2 * c] = (float)((pm - 2.0 * pv * mean) / n);
-    coef[2 * c + 1] = (float)(2.0 * pv / n);
+  const double nv = norms[0], nm = norms[1], w = (double)L.weight;
+  for (int c = threadIdx.x; c < L.C; c += kBlock) {
+    double mean, var;
+    channel_stats(c, mean, var);
+    const double pv = nv > 0.0 ? -((double)running_var[L.chan_off + c] - var) / nv : 0.0;   // d r / d var_c
+    const double pm = nm > 0.0 ? -((double)running_mean[L.chan_off + c] - mean) / nm : 0.0; // d r / d mean_c
+    coef[2 * (L.chan_off + c)] = (float)(w * (pm - 2.0 * pv * mean) / n);
+    coef[2 * (L.chan_off + c) + 1] = (float)(w * 2.0 * pv / n);
+  }
+  if (threadIdx.x == 0) {
+    layer_values[blockIdx.x] = w * (nv + nm);
+    __threadfence();
+    finisher = atomicAdd(counter, 1u) == (unsigned int)n_layers - 1u;
+  }
+  __syncthreads();
+  if (!finisher || threadIdx.x != 0) return;
+  __threadfence();
+  // reference order (regularizers.py:222-227): fp32 adds layer by layer; here fp64, rounded once
+  double sum = 0.0;
+  for (int l = 0; l < n_layers; ++l) sum += layer_values[l];
+  total[0] = (float)sum;
+  *counter = 0u;
+}
+
+// One workgroup per backward item: BH_BN_TILE consecutive elements of one layer (16-byte vectors when HW % 4 == 0).
+__global__ __launch_bounds__(kBlock) void bn_bwd_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
+                                                        const bh_bn_item* __restrict__ items,
+                                                        const float* __restrict__ coef, const float* __restrict__ gout,
+                                                        float* __restrict__ grad_flat) {
+  const bh_bn_item it = items[blockIdx.x];
+  const bh_bn_layer L = layers[it.layer];
+  const float* __restrict__ x = ptrs.p[it.layer];
+  float* __restrict__ o = grad_flat + L.flat_off;
+  const float g = gout ? gout[0] : 1.f;
+  const float2* __restrict__ ab = reinterpret_cast<const float2*>(coef) + L.chan_off;
+  const uint32_t begin = (uint32_t)it.a, count = (uint32_t)it.b;  // in float4s when vectorised, floats otherwise
+  if ((L.HW & 3) == 0) {
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
+    const uint32_t unit = (uint32_t)(L.HW >> 2);
+    float4 q[4];
+    float2 k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = threadIdx.x + u * kBlock;
+      if (i < count) {
+        uint32_t plane, j, bidx, c;
+        fast_divmod(begin + i, unit, L.div_unit_mul, L.div_unit_shr, plane, j);
+        fast_divmod(plane, (uint32_t)L.C, L.div_c_mul, L.div_c_shr, bidx, c);
+        q[u] = x4[begin + i];
+        k[u] = ab[c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = threadIdx.x + u * kBlock;
+      if (i < count) {
+        const float a = g * k[u].x, b = g * k[u].y;
+        o4[begin + i] = make_float4(fmaf(b, q[u].x, a), fmaf(b, q[u].y, a), fmaf(b, q[u].z, a), fmaf(b, q[u].w, a));
+      }
+    }
+  } else {
+    const uint32_t unit = (uint32_t)L.HW;
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
+      uint32_t plane, j, bidx, c;
+      fast_divmod(begin + i, unit, L.div_unit_mul, L.div_unit_shr, plane, j);
+      fast_divmod(plane, (uint32_t)L.C, L.div_c_mul, L.div_c_shr, bidx, c);
+      const float2 kk = ab[c];
+      o[begin + i] = fmaf(g * kk.y, x[begin + i], g * kk.x);
+    }
   }
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void bnstat_bwd_kernel(const float* __restrict__ x, int C, int64_t HW, int64_t total,
-                                                            const float* __restrict__ coef, const float* __restrict__ gout,
-                                                            float* __restrict__ grad) {
-  const float g = gout ? gout[0] : 1.f;
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  if constexpr (VEC) {
-    const int64_t total4 = total >> 2, hw4 = HW >> 2;
-    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
-    float4* __restrict__ g4 = reinterpret_cast<float4*>(grad);
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total4; i += stride) {
-      const int c = (int)((i / hw4) % C);
-      const float a = g * coef[2 * c], b = g * coef[2 * c + 1];
-      const float4 q = x4[i];
-      g4[i] = make_float4(fmaf(b, q.x, a), fmaf(b, q.y, a), fmaf(b, q.z, a), fmaf(b, q.w, a));
-    }
-  } else {
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += stride) {
-      const int c = (int)((i / HW) % C);
-      grad[i] = fmaf(g * coef[2 * c + 1], x[i], g * coef[2 * c]);
-    }
+// host: multiplier / shift of fast_divmod
+void find_divisor(uint32_t d, uint32_t& mul, uint32_t& shr) {
+  if (d <= 1u) {
+    mul = 0u;
+    shr = 0u;
+    return;
   }
+  uint32_t lg = 0;
+  while ((1ull << lg) < d) ++lg;  // ceil(log2 d)
+  const uint32_t p = 31u + lg;
+  mul = (uint32_t)(((1ull << p) + d - 1ull) / d);
+  shr = p - 32u;
+}
+
+constexpr int64_t kBnTargetPerGroup = 8192;  // elements one forward workgroup should see, roughly
+constexpr int64_t kBnNarrowLimit = 2048;     // B * HW below this: one wavefront per channel
+
+struct BnGeometry {
+  int32_t S, narrow;
+  int64_t fwd_items, bwd_items, flat;
+};
+
+bool bn_geometry(int32_t B, int32_t C, int32_t HW, BnGeometry& g) {
+  if (B <= 0 || C <= 0 || HW <= 0) return false;
+  const int64_t per_channel = (int64_t)B * HW, numel = per_channel * C;
+  if (numel >= (int64_t)1 << 31) return false;  // 32-bit indices inside a layer
+  g.narrow = per_channel < kBnNarrowLimit ? 1 : 0;
+  int64_t S = g.narrow ? 1 : (per_channel + kBnTargetPerGroup / 2) / kBnTargetPerGroup;
+  if (S < 1) S = 1;
+  if (S > 64) S = 64;
+  g.S = (int32_t)S;
+  g.fwd_items = g.narrow ? (C + bh::kWavesPerBlock - 1) / bh::kWavesPerBlock : (int64_t)C * S;
+  const int64_t units = (HW & 3) == 0 ? numel / 4 : numel;
+  const int64_t per_item = (HW & 3) == 0 ? BH_BN_TILE / 4 : BH_BN_TILE;
+  g.bwd_items = (units + per_item - 1) / per_item;
+  g.flat = (numel + 3) & ~int64_t(3);
+  return true;
 }
 
 }  // namespace
@@ -338,54 +460,126 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
   return rc != 0 ? rc : grid;
 }
 
-int32_t bh_bnstat_slabs(int32_t B, int32_t C, int64_t HW) {
-  if (B <= 0 || C <= 0 || HW <= 0) return BH_EINVAL;
-  const int64_t items = (int64_t)B * ((HW + kBnTile - 1) / kBnTile);
-  int64_t want = (2048 + C - 1) / C;  // aim for >= 2048 workgroups in total (8 per CU)
-  if (want > items) want = items;
-  if (want < 1) want = 1;
-  if (want > 64) want = 64;
-  return (int32_t)want;
-}
-
-int bh_bnstat_sums(const float* x, int32_t B, int32_t C, int64_t HW, double* sums_dev, void* stream) {
-  if (x == nullptr || sums_dev == nullptr) return BH_EINVAL;
-  const int S = bh_bnstat_slabs(B, C, HW);
-  if (S <= 0) return BH_EINVAL;
-  if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) != 0) return BH_EINVAL;
-  hipLaunchKernelGGL(bnstat_sums_kernel, dim3(C, S), dim3(kBlock), 0, bh::as_stream(stream), x, B, C, HW, S, sums_dev);
-  const int rc = bh::launch_status();
-  return rc != 0 ? rc : S;
-}
-
-int bh_bnstat_finalize(const double* sums_dev, int32_t B, int32_t C, int64_t HW, const float* running_mean,
-                       const float* running_var, float* value_dev, float* coef_dev, double* scratch_dev, void* stream) {
-  if (sums_dev == nullptr || running_mean == nullptr || running_var == nullptr || value_dev == nullptr ||
-      coef_dev == nullptr || scratch_dev == nullptr)
+int bh_bn_plan_size(int32_t n_layers, const int32_t* B, const int32_t* C, const int32_t* HW, int64_t* n_fwd_items,
+                    int64_t* n_bwd_items, int64_t* flat_elems, int64_t* n_sum_pairs, int64_t* n_channels) {
+  if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || B == nullptr || C == nullptr || HW == nullptr ||
+      n_fwd_items == nullptr || n_bwd_items == nullptr || flat_elems == nullptr || n_sum_pairs == nullptr ||
+      n_channels == nullptr)
     return BH_EINVAL;
-  const int S = bh_bnstat_slabs(B, C, HW);
-  if (S <= 0) return BH_EINVAL;
-  hipLaunchKernelGGL(bnstat_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), sums_dev, B, C, HW, S,
-                     running_mean, running_var, value_dev, coef_dev, scratch_dev);
+  int64_t fwd = 0, bwd = 0, flat = 0, pairs = 0, chans = 0;
+  for (int32_t l = 0; l < n_layers; ++l) {
+    BnGeometry g;
+    if (!bn_geometry(B[l], C[l], HW[l], g)) return BH_EINVAL;
+    fwd += g.fwd_items;
+    bwd += g.bwd_items;
+    flat += g.flat;
+    pairs += (int64_t)C[l] * g.S;
+    chans += C[l];
+  }
+  if (fwd > INT32_MAX || bwd > INT32_MAX || chans > INT32_MAX) return BH_EINVAL;
+  *n_fwd_items = fwd;
+  *n_bwd_items = bwd;
+  *flat_elems = flat;
+  *n_sum_pairs = pairs;
+  *n_channels = chans;
+  return 0;
+}
+
+int bh_bn_plan_build(int32_t n_layers, const int32_t* B, const int32_t* C, const int32_t* HW, const float* weights,
+                     bh_bn_layer* layers, bh_bn_item* fwd_items, int64_t n_fwd_items, bh_bn_item* bwd_items,
+                     int64_t n_bwd_items) {
+  int64_t fwd = 0, bwd = 0, flat = 0, pairs = 0, chans = 0;
+  int rc = bh_bn_plan_size(n_layers, B, C, HW, &fwd, &bwd, &flat, &pairs, &chans);
+  if (rc != 0) return rc;
+  if (fwd != n_fwd_items || bwd != n_bwd_items || layers == nullptr || fwd_items == nullptr || bwd_items == nullptr)
+    return BH_EINVAL;
+  int64_t fi = 0, bi = 0;
+  flat = pairs = chans = 0;
+  for (int32_t l = 0; l < n_layers; ++l) {
+    BnGeometry g;
+    bn_geometry(B[l], C[l], HW[l], g);
+    bh_bn_layer& L = layers[l];
+    L.flat_off = flat;
+    L.sums_off = pairs;
+    L.chan_off = (int32_t)chans;
+    L.B = B[l];
+    L.C = C[l];
+    L.HW = HW[l];
+    L.S = g.S;
+    L.narrow = g.narrow;
+    L.weight = weights ? weights[l] : 1.f;
+    const bool vec = (HW[l] & 3) == 0;
+    find_divisor((uint32_t)(vec ? HW[l] / 4 : HW[l]), L.div_unit_mul, L.div_unit_shr);
+    find_divisor((uint32_t)C[l], L.div_c_mul, L.div_c_shr);
+    if (g.narrow) {
+      for (int32_t c = 0; c < C[l]; c += bh::kWavesPerBlock) fwd_items[fi++] = bh_bn_item{l, c, 0, 0};
+    } else {
+      for (int32_t c = 0; c < C[l]; ++c)
+        for (int32_t s = 0; s < g.S; ++s) fwd_items[fi++] = bh_bn_item{l, c, s, 0};
+    }
+    const int64_t numel = (int64_t)B[l] * C[l] * HW[l];
+    const int64_t units = vec ? numel / 4 : numel, per_item = vec ? BH_BN_TILE / 4 : BH_BN_TILE;
+    for (int64_t u = 0; u < units; u += per_item) {
+      const int64_t cnt = (units - u) < per_item ? (units - u) : per_item;
+      bwd_items[bi++] = bh_bn_item{l, (int32_t)u, (int32_t)cnt, 0};
+    }
+    flat += g.flat;
+    pairs += (int64_t)C[l] * g.S;
+    chans += C[l];
+  }
+  return (fi == n_fwd_items && bi == n_bwd_items) ? 0 : BH_EINVAL;
+}
+
+namespace {
+bool fill_bn_ptrs(BnPtrs& out, const void* const* x_ptrs, int32_t n_layers, const int32_t* hw_host) {
+  for (int32_t l = 0; l < n_layers; ++l) {
+    const void* p = x_ptrs[l];
+    if (p == nullptr) return false;
+    if (hw_host != nullptr && (hw_host[l] & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) != 0) return false;
+    out.p[l] = static_cast<const float*>(p);
+  }
+  for (int32_t l = n_layers; l < BH_BN_MAX_LAYERS; ++l) out.p[l] = nullptr;
+  return true;
+}
+}  // namespace
+
+int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
+               const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, void* stream) {
+  if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || x_ptrs == nullptr || hw_host == nullptr || layers_dev == nullptr ||
+      fwd_items_dev == nullptr || n_fwd_items <= 0 || n_fwd_items > INT32_MAX || sums_dev == nullptr)
+    return BH_EINVAL;
+  BnPtrs ptrs;
+  if (!fill_bn_ptrs(ptrs, x_ptrs, n_layers, hw_host)) return BH_EINVAL;
+  hipLaunchKernelGGL(bn_sums_kernel, dim3((unsigned int)n_fwd_items), dim3(kBlock), 0, bh::as_stream(stream), ptrs,
+                     layers_dev, fwd_items_dev, sums_dev);
   return bh::launch_status();
 }
 
-int bh_bnstat_bwd(const float* x, int32_t B, int32_t C, int64_t HW, const float* coef_dev, const float* gout_dev,
-                  float* grad_x, void* stream) {
-  if (x == nullptr || coef_dev == nullptr || grad_x == nullptr || B <= 0 || C <= 0 || HW <= 0) return BH_EINVAL;
-  const int64_t total = (int64_t)B * C * HW;
-  const bool vec = (HW & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 &&
-                   (reinterpret_cast<uintptr_t>(grad_x) & 15u) == 0;
-  const int64_t work = vec ? (total >> 2) : total;
-  int64_t blocks = (work + kBlock - 1) / kBlock;
-  if (blocks > 4096) blocks = 4096;
-  hipStream_t st = bh::as_stream(stream);
-  if (vec)
-    hipLaunchKernelGGL(bnstat_bwd_kernel<true>, dim3((int)blocks), dim3(kBlock), 0, st, x, C, HW, total, coef_dev,
-                       gout_dev, grad_x);
-  else
-    hipLaunchKernelGGL(bnstat_bwd_kernel<false>, dim3((int)blocks), dim3(kBlock), 0, st, x, C, HW, total, coef_dev,
-                       gout_dev, grad_x);
+int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double* sums_dev, const float* running_mean,
+                   const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
+                   void* counter_dev, void* stream) {
+  if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || layers_dev == nullptr || sums_dev == nullptr ||
+      running_mean == nullptr || running_var == nullptr || coef_dev == nullptr || layer_values_dev == nullptr ||
+      total_dev == nullptr || counter_dev == nullptr)
+    return BH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(coef_dev) & 7u) != 0) return BH_EINVAL;  // read back as float2
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(n_layers), dim3(kBlock), 0, bh::as_stream(stream), n_layers, layers_dev,
+                     sums_dev, running_mean, running_var, coef_dev, layer_values_dev, total_dev,
+                     static_cast<unsigned int*>(counter_dev));
+  return bh::launch_status();
+}
+
+int bh_bn_bwd(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
+              const bh_bn_item* bwd_items_dev, int64_t n_bwd_items, const float* coef_dev, const float* gout_dev,
+              float* grad_flat, void* stream) {
+  if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || x_ptrs == nullptr || hw_host == nullptr || layers_dev == nullptr ||
+      bwd_items_dev == nullptr || n_bwd_items <= 0 || n_bwd_items > INT32_MAX || coef_dev == nullptr ||
+      grad_flat == nullptr || (reinterpret_cast<uintptr_t>(grad_flat) & 15u) != 0)
+    return BH_EINVAL;
+  BnPtrs ptrs;
+  if (!fill_bn_ptrs(ptrs, x_ptrs, n_layers, hw_host)) return BH_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((unsigned int)n_bwd_items), dim3(kBlock), 0, bh::as_stream(stream), ptrs,
+                     layers_dev, bwd_items_dev, coef_dev, gout_dev, grad_flat);
   return bh::launch_status();
 }
 

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void candidate_step_kernel(const Word* __re
   const float decay = (float)row[2];
   const float noise_coef = noise ? (float)((double)P.langevin * row[3]) : 0.f;
   float clip_mul = 1.f;
-  if (P.grad_clip > 0.f) {
+  if (P.grad_clip >= 0.f) {  // negative: clipping off (optim.grad_clip = None)
     const float gn = st[BH_STATE_GNORM].f;
     if (gn > P.grad_clip) clip_mul = P.grad_clip / (gn + 1e-6f);  // :173-174
   }

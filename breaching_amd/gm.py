@@ -12,12 +12,17 @@ per-parameter gradient list and its derivative run here.
 """
 
 import ctypes
+import os
 from ctypes import c_int32, c_int64, c_void_p
 
 import torch
 from torch.autograd.function import once_differentiable
 
 from . import _lib
+
+
+# forward + finalize as one launch (last-arriver epilogue); BREACH_HIP_FUSED_FINALIZE=0 selects the two-launch form
+FUSED_FINALIZE = os.environ.get("BREACH_HIP_FUSED_FINALIZE", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -46,6 +51,15 @@ class GradientMatchPlan:
             _require_cuda(t, "observed gradient")
             if t.dtype != torch.float32:
                 raise NotImplementedError(f"HIP gradient matching computes in fp32; got {t.dtype} (impl.dtype must be float).")
+        # Identity of the list this plan was packed from: strong references to the caller's tensors (plain data, no
+        # autograd graph) plus their version counters.  An address can be recycled by the caching allocator once a list is
+        # freed (one attacker reused for user after user, benchmark_breaches.py:60-70), so addresses prove nothing;
+        # object identity of tensors that are kept alive does, and the version counter catches in-place edits.
+        self._sources = tuple(tensors)
+        self._versions = tuple(t._version for t in tensors)
+        # packed in logical (row-major) order whatever the caller's strides are: the reconstructed gradients are compared
+        # element by element in that order (a channels_last user gradient must not be packed in its physical order)
+        tensors = [t if t.is_contiguous() else t.contiguous() for t in tensors]
         self.device = tensors[0].device
         self.n_tensors = len(tensors)
         self.shapes = [tuple(t.shape) for t in tensors]
@@ -65,13 +79,14 @@ class GradientMatchPlan:
         n_groups = lib.bh_gm_num_groups(self.n_tensors)
         self._group_bounds = (c_int32 * (n_groups + 1))()
         _lib.check(lib.bh_gm_group_bounds(self.n_tensors, self._chunks_host, self.n_chunks, self._group_bounds), "bh_gm_group_bounds")
+        # rows of the forward workspace: one per persistent workgroup (<= 2048 per launch group)
+        self.n_rows = _lib.check(lib.bh_gm_fwd_rows(self.n_tensors, self._group_bounds), "bh_gm_fwd_rows")
 
         # device copies
         raw = torch.frombuffer(bytearray(bytes(self._chunks_host)), dtype=torch.uint8)
         self.chunks_dev = raw.to(self.device)
         self.data_flat = torch.empty(max(self.flat_elems, 4), dtype=torch.float32, device=self.device)
         self._dummy = torch.zeros(4, dtype=torch.float32, device=self.device)
-        self._data_ptr_key = tuple(t.data_ptr() for t in tensors[:4])
         with torch.cuda.device(self.device):
             srcs = self._pointer_array(tensors)
             _lib.check(
@@ -153,30 +168,47 @@ class GradientMatchPlan:
         # carry their autograd graph) would keep stale AccumulateGrad nodes alive and break hipGraph capture.
         return (c_void_p * len(addrs))(*addrs)
 
-    def matches(self, gradient_data):
-        n = min(len(gradient_data), self.n_tensors)
-        return len(gradient_data) >= self.n_tensors and tuple(t.data_ptr() for t in gradient_data[: min(4, n)]) == self._data_ptr_key
+    def matches(self, gradient_data, n_pairs):
+        """True when this plan was packed from exactly these tensor objects and none was written to since."""
+        if n_pairs != self.n_tensors or len(gradient_data) < n_pairs:
+            return False
+        for i in range(n_pairs):
+            t = gradient_data[i]
+            if t is not self._sources[i] or t._version != self._versions[i]:
+                return False
+        return True
 
     # -- launches --------------------------------------------------------------------------------------------------
-    def forward(self, kind, rec, scale, tag_scale=0.0, fudge=1e-7, weights=None):
-        """Enqueue forward + finalize; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS]."""
+    def forward(self, kind, rec, scale, tag_scale=0.0, fudge=1e-7, weights=None, ticket=None, fused=True):
+        """Enqueue the forward reduction; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS].
+
+        One launch: the last workgroup combines the rows and writes the record (``fused``).  ``ticket`` is the zeroed
+        int32 device word that launch uses to find its last workgroup; the finisher re-zeroes it, so a caller that issues
+        its forwards on one stream passes the same word every time (``FusedTrial`` owns one per plan).  Without a ticket a
+        fresh zero word is made for the call.  ``fused=False`` runs the stand-alone finalize kernel instead."""
         lib = _lib.load()
         stats = torch.empty(_lib.BH_GM_STAT_WORDS, dtype=torch.float32, device=self.device)
-        # per-call workspace (92 KB for ResNet-18): trials that run concurrently on different streams share this plan
-        partials = torch.empty(self.n_chunks * _lib.BH_GM_PARTIAL_STRIDE, dtype=torch.float64, device=self.device)
+        # per-call workspace (64 KB): trials that run concurrently on different streams share this plan
+        partials = torch.empty(self.n_rows * _lib.BH_GM_PARTIAL_STRIDE, dtype=torch.float64, device=self.device)
         stream = _lib.current_stream_handle(self.device)
         ptrs = self._pointer_array(rec)
         ev0, ev1 = self._timed("fwd")
+        epilogue = None
+        if fused:
+            if ticket is None:
+                ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
+            epilogue = _lib.GmFused(_lib.ptr(ticket), _lib.ptr(stats), _lib.ptr(self.span_accum), float(scale), float(fudge))
         _lib.check(
             lib.bh_gm_fwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), stream, ev0, ev1),
+                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), epilogue, stream, ev0, ev1),
             "bh_gm_fwd",
         )
-        _lib.check(
-            lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_chunks, float(scale), float(tag_scale), float(fudge),
-                               _lib.ptr(stats), _lib.ptr(self.span_accum), stream),
-            "bh_gm_finalize",
-        )
+        if not fused:
+            _lib.check(
+                lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_rows, float(scale), float(tag_scale), float(fudge),
+                                   _lib.ptr(stats), _lib.ptr(self.span_accum), stream),
+                "bh_gm_finalize",
+            )
         return stats
 
     def backward(self, kind, rec, stats, gout, weights=None):
@@ -201,10 +233,10 @@ class _GradMatchFunction(torch.autograd.Function):
     """objective(rec_0, ..., rec_{T-1}) as one differentiable node; backward hands autograd T views of one buffer."""
 
     @staticmethod
-    def forward(ctx, plan, kind, scale, tag_scale, fudge, weights, *rec):
+    def forward(ctx, plan, kind, scale, tag_scale, fudge, weights, ticket, *rec):
         rec = plan._prepare(rec)
         with torch.cuda.device(plan.device):
-            stats = plan.forward(kind, rec, scale, tag_scale, fudge, weights)
+            stats = plan.forward(kind, rec, scale, tag_scale, fudge, weights, ticket=ticket, fused=FUSED_FINALIZE)
         ctx.plan, ctx.kind, ctx.weights, ctx.stats = plan, kind, weights, stats
         ctx.n_inputs = len(rec)
         ctx.save_for_backward(*rec)
@@ -219,7 +251,7 @@ class _GradMatchFunction(torch.autograd.Function):
         with torch.cuda.device(plan.device):
             grad_flat = plan.backward(ctx.kind, rec, ctx.stats, gout, ctx.weights)
         grads = plan.split(grad_flat)
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class HipGradientLoss(torch.nn.Module):
@@ -231,7 +263,13 @@ class HipGradientLoss(torch.nn.Module):
         super().__init__()
         self.scale = scale
         self.task_regularization = task_regularization
-        self._plan = None
+        self._plans = []
+        self.ticket_scope = None
+
+    @property
+    def _plan(self):
+        """The most recently used plan (bench.py reads its timers); None before the first objective evaluation."""
+        return self._plans[0] if self._plans else None
 
     # objectives.py:16-24
     def initialize(self, loss_fn, cfg_impl, local_hyperparams=None):
@@ -241,6 +279,17 @@ class HipGradientLoss(torch.nn.Module):
         if getattr(cfg_impl, "mixed_precision", False):
             raise NotImplementedError("The HIP gradient-matching path is fp32 only (impl.mixed_precision must be False).")
         self._grad_fn = self._single_step_gradient if local_hyperparams is None else self._multi_step_update
+        # A new trial (or a new user: the reference builds the attacker once and calls reconstruct per user,
+        # benchmark_breaches.py:60-70) starts from freshly packed observed gradients -- 20 us -- never from a cached plan.
+        self._plans = []
+
+    def prepare(self, models, shared_data):
+        """Pack every observed gradient list now, on the current stream (one plan per model / query).  Called before the
+        loop so that no plan is ever built inside it (a build does a blocking host-to-device copy, which a hipGraph
+        capture cannot contain) and before trials fork onto side streams (they only read the plans)."""
+        for model, data in zip(models, shared_data):
+            n_rec = sum(1 for _ in model.parameters())
+            self._plan_for_count(n_rec, data["gradients"])
 
     # objectives.py:26-32
     def forward(self, model, gradient_data, candidate, labels):
@@ -251,11 +300,15 @@ class HipGradientLoss(torch.nn.Module):
         return objective, task_loss.detach()
 
     def _plan_for(self, gradient_rec, gradient_data):
-        n_pairs = min(len(gradient_rec), len(gradient_data))
-        plan = self._plan
-        if plan is None or plan.n_tensors != n_pairs or not plan.matches(gradient_data):
-            plan = GradientMatchPlan(gradient_data, n_pairs)
-            self._plan = plan
+        return self._plan_for_count(len(gradient_rec), gradient_data)
+
+    def _plan_for_count(self, n_rec, gradient_data):
+        n_pairs = min(n_rec, len(gradient_data))
+        for plan in self._plans:
+            if plan.matches(gradient_data, n_pairs):
+                return plan
+        plan = GradientMatchPlan(gradient_data, n_pairs)
+        self._plans.append(plan)  # one plan per observed list: multi-query / multi-model payloads alternate between them
         return plan
 
     def _weights(self, plan, n_rec):
@@ -272,7 +325,20 @@ class HipGradientLoss(torch.nn.Module):
         tag_scale, fudge = self._extra()
         kind = _lib.GM_KINDS[self.kind_name]
         return _GradMatchFunction.apply(plan, kind, float(self.scale), tag_scale, fudge,
-                                        self._weights(plan, len(gradient_rec)), *gradient_rec[: plan.n_tensors])
+                                        self._weights(plan, len(gradient_rec)), self._ticket(plan),
+                                        *gradient_rec[: plan.n_tensors])
+
+    def _ticket(self, plan):
+        """The zeroed device word the fused forward uses to find its last workgroup.  Inside a ``ticket_scope`` (a dict owned
+        by one trial, whose forwards are all on one stream) one word per plan is reused forever -- the finisher re-zeroes
+        it; outside (scoring, L-BFGS closures) every call gets a fresh word."""
+        scope = self.ticket_scope
+        if scope is None:
+            return None
+        ticket = scope.get(id(plan))
+        if ticket is None:
+            ticket = scope[id(plan)] = torch.zeros(1, dtype=torch.int32, device=plan.device)
+        return ticket
 
     # objectives.py:40-46
     def _single_step_gradient(self, model, candidate, labels):

@@ -118,54 +118,109 @@ class HipNormRegularization(torch.nn.Module):
 # ---------------------------------------------------------------------------------------------------------------
 
 
+def _upload(ctypes_array, device):
+    """Host ctypes table -> device bytes (blocking copy; done once per plan, never inside the loop)."""
+    return torch.frombuffer(bytearray(bytes(ctypes_array)), dtype=torch.uint8).to(device)
+
+
+class BnStatPlan:
+    """Static state of kernel D for one model: geometry tables of all BatchNorm inputs, packed running statistics,
+    layer weights.  Built at the first evaluation of a trial (the input shapes are known only after a forward pass)."""
+
+    def __init__(self, shapes, running_means, running_vars, weights, device):
+        import ctypes
+        from ctypes import c_float, c_int32, c_int64
+
+        lib = _lib.load()
+        n = len(shapes)
+        if n == 0 or n > _lib.BH_BN_MAX_LAYERS:
+            raise ValueError(f"DeepInversion prior supports 1..{_lib.BH_BN_MAX_LAYERS} BatchNorm layers, got {n}.")
+        self.device = device
+        self.n_layers = n
+        self.shapes = [tuple(s) for s in shapes]
+        B = (c_int32 * n)(*[s[0] for s in shapes])
+        C = (c_int32 * n)(*[s[1] for s in shapes])
+        hw = [int(torch.Size(s[2:]).numel()) if len(s) > 2 else 1 for s in shapes]
+        self.hw_host = (c_int32 * n)(*hw)
+        sizes = [c_int64(0) for _ in range(5)]
+        _lib.check(lib.bh_bn_plan_size(n, B, C, self.hw_host, *[ctypes.byref(v) for v in sizes]), "bh_bn_plan_size")
+        self.n_fwd, self.n_bwd, self.flat_elems, self.n_pairs, self.n_channels = [v.value for v in sizes]
+        layers = (_lib.BnLayer * n)()
+        fwd = (_lib.BnItem * self.n_fwd)()
+        bwd = (_lib.BnItem * self.n_bwd)()
+        w = (c_float * n)(*[float(v) for v in weights])
+        _lib.check(lib.bh_bn_plan_build(n, B, C, self.hw_host, w, layers, fwd, self.n_fwd, bwd, self.n_bwd), "bh_bn_plan_build")
+        self.flat_offsets = [layers[i].flat_off for i in range(n)]
+        self.numels = [int(torch.Size(s).numel()) for s in shapes]
+        self.layers_dev, self.fwd_dev, self.bwd_dev = _upload(layers, device), _upload(fwd, device), _upload(bwd, device)
+        self.running_mean = torch.cat([m.detach().to(torch.float32).reshape(-1) for m in running_means]).contiguous()
+        self.running_var = torch.cat([v.detach().to(torch.float32).reshape(-1) for v in running_vars]).contiguous()
+
+    def matches(self, shapes):
+        return len(shapes) == self.n_layers and all(tuple(a) == b for a, b in zip(shapes, self.shapes))
+
+    def pointers(self, xs):
+        from ctypes import c_void_p
+
+        return (c_void_p * self.n_layers)(*[x.data_ptr() for x in xs])
+
+
 class _BnStatFunction(torch.autograd.Function):
-    """r(x) = ||running_var - var_c(x)||_2 + ||running_mean - mean_c(x)||_2 for one BN input x[B,C,H,W]."""
+    """total(x_0 .. x_{L-1}) = sum_l weight_l * (||running_var_l - var_c(x_l)||_2 + ||running_mean_l - mean_c(x_l)||_2)
+    as ONE autograd node over all BatchNorm inputs: three launches forward+backward for the whole model."""
 
     @staticmethod
-    def forward(ctx, x, running_mean, running_var):
+    def forward(ctx, plan, ticket, *xs):
         lib = _lib.load()
-        if not x.is_cuda or x.dtype != torch.float32:
-            raise RuntimeError("HIP DeepInversion prior needs fp32 activations on a ROCm device (no CPU fallback).")
-        xc = x.detach().contiguous()
-        if xc.data_ptr() % 16:
-            xc = xc.clone()
-        B, C = xc.shape[0], xc.shape[1]
-        HW = xc.numel() // (B * C)
-        dev = xc.device
+        prepared = []
+        for x, hw in zip(xs, plan.hw_host):
+            if not x.is_cuda or x.dtype != torch.float32:
+                raise RuntimeError("HIP DeepInversion prior needs fp32 activations on a ROCm device (no CPU fallback).")
+            xc = x.detach().contiguous()
+            if hw % 4 == 0 and xc.data_ptr() % 16:
+                xc = xc.clone()
+            prepared.append(xc)
+        dev = plan.device
         with torch.cuda.device(dev):
             stream = _lib.current_stream_handle(dev)
-            S = lib.bh_bnstat_slabs(B, C, HW)
-            sums = torch.empty(C * S * 2, dtype=torch.float64, device=dev)
-            scratch = torch.empty(2 * C, dtype=torch.float64, device=dev)
-            out = torch.empty(1 + 2 * C, dtype=torch.float32, device=dev)  # [value | coef(2C)]
-            _lib.check(lib.bh_bnstat_sums(_lib.ptr(xc), B, C, HW, _lib.ptr(sums), stream), "bh_bnstat_sums")
-            rm = running_mean.detach().to(torch.float32).contiguous()
-            rv = running_var.detach().to(torch.float32).contiguous()
-            _lib.check(
-                lib.bh_bnstat_finalize(_lib.ptr(sums), B, C, HW, _lib.ptr(rm), _lib.ptr(rv), _lib.ptr(out),
-                                       ctypes_offset(out, 1), _lib.ptr(scratch), stream),
-                "bh_bnstat_finalize",
-            )
-        ctx.save_for_backward(xc, out)
-        ctx.dims = (B, C, HW)
-        ctx.in_shape = x.shape
-        return out[0]
+            sums = torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=dev)
+            layer_values = torch.empty(plan.n_layers, dtype=torch.float64, device=dev)
+            coef = torch.empty(2 * plan.n_channels, dtype=torch.float32, device=dev)
+            total = torch.empty(1, dtype=torch.float32, device=dev)
+            if ticket is None:
+                ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+            ptrs = plan.pointers(prepared)
+            _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
+                                      plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
+            _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
+                                          _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
+                                          _lib.ptr(ticket), stream), "bh_bn_finalize")
+        ctx.plan = plan
+        ctx.save_for_backward(coef, *prepared)
+        ctx.in_shapes = [x.shape for x in xs]
+        return total[0]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
         lib = _lib.load()
-        xc, out = ctx.saved_tensors
-        B, C, HW = ctx.dims
-        grad = torch.empty_like(xc)
+        plan = ctx.plan
+        coef, *xs = ctx.saved_tensors
+        dev = plan.device
+        grad_flat = torch.empty(max(plan.flat_elems, 4), dtype=torch.float32, device=dev)
         gout = gout.contiguous().to(torch.float32)
-        with torch.cuda.device(xc.device):
-            _lib.check(
-                lib.bh_bnstat_bwd(_lib.ptr(xc), B, C, HW, ctypes_offset(out, 1), _lib.ptr(gout), _lib.ptr(grad),
-                                  _lib.current_stream_handle(xc.device)),
-                "bh_bnstat_bwd",
-            )
-        return grad.view(ctx.in_shape), None, None
+        with torch.cuda.device(dev):
+            _lib.check(lib.bh_bn_bwd(plan.n_layers, plan.pointers(xs), plan.hw_host, _lib.ptr(plan.layers_dev),
+                                     _lib.ptr(plan.bwd_dev), plan.n_bwd, _lib.ptr(coef), _lib.ptr(gout), _lib.ptr(grad_flat),
+                                     _lib.current_stream_handle(dev)), "bh_bn_bwd")
+        grads = [grad_flat[o : o + n].view(s) for o, n, s in zip(plan.flat_offsets, plan.numels, ctx.in_shapes)]
+        return (None, None, *grads)
+
+
+def bn_statistic(x, running_mean, running_var, weight=1.0):
+    """The statistic of a single BatchNorm input (a one-layer plan): used by the kernel tests."""
+    plan = BnStatPlan([x.shape], [running_mean], [running_var], [weight], x.device)
+    return _BnStatFunction.apply(plan, None, x)
 
 
 def ctypes_offset(tensor, elements):
@@ -174,17 +229,17 @@ def ctypes_offset(tensor, elements):
     return c_void_p(tensor.data_ptr() + elements * tensor.element_size())
 
 
-class _BnStatHook:
-    """Forward hook on one BatchNorm2d: keeps the feature statistic of the module's *input* (deepinversion.py:93-101)."""
+class _BnInputHook:
+    """Forward hook on one BatchNorm2d: keeps the module's *input* of the latest forward pass (the reference computes the
+    statistic right inside its hook, deepinversion.py:93-101; here all layers are evaluated together afterwards)."""
 
     def __init__(self, module):
-        self.r_feature = None
+        self.module = module
+        self.x = None
         self.handle = module.register_forward_hook(self)
 
     def __call__(self, module, inputs, output):
-        if module.running_mean is None or module.running_var is None:
-            raise RuntimeError("DeepInversion prior needs BatchNorm running statistics (buffers) on the attacked model.")
-        self.r_feature = _BnStatFunction.apply(inputs[0], module.running_mean, module.running_var)
+        self.x = inputs[0]
 
     def close(self):
         self.handle.remove()
@@ -199,6 +254,8 @@ class HipDeepInversion(torch.nn.Module):
         self.scale = scale
         self.first_bn_multiplier = first_bn_multiplier
         self.losses = []
+        self._plans = {}
+        self.ticket_scope = None  # dict owned by a trial: one re-zeroed ticket word per model (see gm.HipGradientLoss)
 
     def initialize(self, models, *args, **kwargs):
         # The reference re-registers hooks on every trial and never removes the old ones (regularizers.py:214-220);
@@ -207,23 +264,47 @@ class HipDeepInversion(torch.nn.Module):
             for hook in hooks:
                 hook.close()
         self.losses = [list() for _ in models]
+        self._plans = {}
         for idx, model in enumerate(models):
             for module in model.modules():
                 if isinstance(module, torch.nn.BatchNorm2d):
-                    self.losses[idx].append(_BnStatHook(module))
+                    self.losses[idx].append(_BnInputHook(module))
 
     def release_graph(self):
-        """Drop the feature statistics of the last forward pass (they hold that pass's autograd graph)."""
+        """Drop the activations of the last forward pass (they hold that pass's autograd graph)."""
         for hooks in self.losses:
             for hook in hooks:
-                hook.r_feature = None
+                hook.x = None
+
+    def _plan(self, idx, hooks, xs):
+        shapes = [x.shape for x in xs]
+        plan = self._plans.get(idx)
+        if plan is None or not plan.matches(shapes):
+            for hook in hooks:
+                if hook.module.running_mean is None or hook.module.running_var is None:
+                    raise RuntimeError("DeepInversion prior needs BatchNorm running statistics (buffers) on the attacked model.")
+            weights = [self.scale * (self.first_bn_multiplier if i == 0 else 1.0) for i in range(len(hooks))]
+            plan = BnStatPlan(shapes, [h.module.running_mean for h in hooks], [h.module.running_var for h in hooks], weights,
+                              xs[0].device)
+            self._plans[idx] = plan
+        return plan
 
     def forward(self, tensor, *args, **kwargs):
-        feature_reg = 0
-        for hooks in self.losses:
-            for idx, hook in enumerate(hooks):
-                feature_reg = feature_reg + hook.r_feature * (self.first_bn_multiplier if idx == 0 else 1.0)
-        return self.scale * feature_reg
+        total = 0
+        for idx, hooks in enumerate(self.losses):
+            if len(hooks) == 0:
+                continue
+            xs = [hook.x for hook in hooks]
+            if any(x is None for x in xs):
+                raise RuntimeError("DeepInversion prior evaluated before a forward pass of the attacked model.")
+            plan = self._plan(idx, hooks, xs)
+            ticket = None
+            if self.ticket_scope is not None:
+                ticket = self.ticket_scope.get(("bn", idx))
+                if ticket is None:
+                    ticket = self.ticket_scope[("bn", idx)] = torch.zeros(1, dtype=torch.int32, device=plan.device)
+            total = total + _BnStatFunction.apply(plan, ticket, *xs)
+        return total
 
     def __repr__(self):
         return (

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 3
+#define BH_ABI_VERSION 4
 #define BH_EINVAL (-1)
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -41,8 +41,10 @@ extern "C" {
 /* Device pointers per launch that travel in the kernel-argument segment.  Longer lists are processed in several
  * launches by the library (transparent to the caller). */
 #define BH_GM_MAX_PTRS 448
-/* Doubles per row of the partial-sum workspace (one row per chunk). */
+/* Doubles per row of the partial-sum workspace (one row per persistent workgroup of the forward launch). */
 #define BH_GM_PARTIAL_STRIDE 4
+/* Workgroups (= rows) of one forward launch group at most: 8 resident 256-thread workgroups per CU on 256 CUs. */
+#define BH_GM_MAX_ROWS 2048
 
 /* One entry of the chunk table (24 bytes, device resident, built once per attack by bh_gm_build_table). */
 typedef struct bh_gm_chunk {
@@ -86,17 +88,37 @@ int bh_gm_table_size(int32_t n_tensors, const int64_t* numel, int64_t* n_chunks,
 int bh_gm_build_table(int32_t n_tensors, const int64_t* numel, bh_gm_chunk* chunks, int64_t n_chunks,
                       int64_t* tensor_flat_off);
 
-/* Forward partial sums.  `rec_ptrs` is a HOST array of `n_tensors` DEVICE pointers (the tensors returned by
+/* Optional fused finalize of bh_gm_fwd: the workgroup that finishes last combines all rows and writes the statistics
+ * record, so forward + finalize is ONE launch.  `counter_dev` is a 4-byte device word that must be zero before the
+ * call; the finisher resets it to zero, so the same word serves every later call on the same stream (calls that may
+ * overlap -- different streams -- need their own word). */
+typedef struct bh_gm_fused {
+  void* counter_dev;      /* uint32 ticket, zero-initialised once by the caller */
+  float* stats_dev;       /* BH_GM_STAT_WORDS floats, as written by bh_gm_finalize */
+  double* span_accum_dev; /* optional, see bh_gm_finalize */
+  float scale;            /* objective scale (`* self.scale`, objectives.py:86, :126, :155, :178) */
+  float fudge;            /* AngularSimilarity clamp margin (objectives.py:208) */
+} bh_gm_fused;
+
+/* Forward reduction.  `rec_ptrs` is a HOST array of `n_tensors` DEVICE pointers (the tensors returned by
  * autograd this iteration, each contiguous fp32 and 16-byte aligned); `data_flat` is the packed observed gradient;
  * `chunks_dev` the device chunk table; `weights_dev` per-tensor fp32 weights (BH_GM_TAG only, else NULL).
- * `partials_dev` (32-byte aligned) must hold n_chunks rows of BH_GM_PARTIAL_STRIDE doubles; row c belongs to chunk c and is
- * overwritten, never accumulated.  `group_chunk_begin` (HOST, bh_gm_num_groups+1 entries, from bh_gm_group_bounds)
- * delimits the chunks of every launch group.
- * reference: objectives.py:89-95, 133-141, 158-166, 183-196, 233-244, 259-273 (the list reductions). */
+ * The launch is a persistent grid: bh_gm_fwd_rows() workgroups, each streaming every G-th chunk and writing ONE row
+ * of BH_GM_PARTIAL_STRIDE doubles into `partials_dev` (32-byte aligned, bh_gm_fwd_rows rows; overwritten, never
+ * accumulated).  `group_chunk_begin` (HOST, bh_gm_num_groups+1 entries, from bh_gm_group_bounds) delimits the chunks
+ * of every launch group.  With `fused` non-NULL the statistics record is complete when the call's work is done; with
+ * NULL the caller follows up with bh_gm_finalize(kind, partials_dev, bh_gm_fwd_rows(...), ...).
+ * reference: objectives.py:89-95, 133-141, 158-166, 183-196, 233-244, 259-273 (the list reductions) and their
+ * epilogues :95, :141, :166, :195, :211-214, :243, :271. */
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
-              void* ev_stop);
+              const float* weights_dev, float tag_scale, double* partials_dev, const bh_gm_fused* fused, void* stream,
+              void* ev_start, void* ev_stop);
+/* Rows (= workgroups over all launch groups) bh_gm_fwd writes for this list: chunks are dealt out evenly to at most
+ * `rows cap` workgroups per launch group (default BH_GM_MAX_ROWS).  Negative on invalid arguments. */
+int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin);
+/* Tuning knob (process global, host side): cap of workgroups per forward launch group, 1..BH_GM_MAX_ROWS. */
+int32_t bh_gm_set_rows_cap(int32_t cap);
 /* `ev_start` / `ev_stop` (here and in bh_gm_bwd): optional hipEvent_t handles from bh_event_create.  When given, the
  * launch goes through hipExtLaunchKernelGGL, so the events carry the dispatch's own begin / end timestamps (the
  * completion-signal times rocprofv3 reports) -- no host latency, no marker overhead.  Not usable during stream
@@ -108,7 +130,8 @@ int32_t bh_gm_num_groups(int32_t n_tensors);
 int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_t n_chunks,
                        int32_t* group_chunk_begin);
 
-/* Fixed-order combine of the partial sums and objective epilogue: writes BH_GM_STAT_WORDS floats to `stats_dev`.
+/* Stand-alone fixed-order combine of the partial rows and objective epilogue (what the fused finisher of bh_gm_fwd
+ * does in-kernel): writes BH_GM_STAT_WORDS floats to `stats_dev`.
  * `fudge` is AngularSimilarity's clamp margin (objectives.py:208, 1e-7); ignored otherwise.
  * reference: objectives.py:95 (0.5*objective), :141, :166, :195, :211-214, :243, :271 and the `* self.scale`
  * at :86, :126, :155, :178. */
@@ -157,24 +180,60 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
  * DeepInversion batch-norm statistics prior ("kernel D")
  * ---------------------------------------------------------------------------------------------------------------- */
 
-/* Slabs per channel used by bh_bnstat_sums for this shape (>= 1); sizes the workspace below. */
-int32_t bh_bnstat_slabs(int32_t B, int32_t C, int64_t HW);
+/* The prior sums, over every BatchNorm2d layer l of the attacked model, a statistic of the layer's INPUT x_l[B,C,H*W]:
+ *   r_l = | running_var - var_c(x_l) |_2 + | running_mean - mean_c(x_l) |_2     (biased variance over b, h, w)
+ *   total = sum_l weight_l * r_l       (weight_l = scale * first_bn_multiplier for l = 0, scale otherwise)
+ * reference: regularizers.py:203-230 (DeepInversion), deepinversion.py:93-101 (the per-layer hook; NVIDIA-NC licensed,
+ * restated from the formula only).  All layers are processed by ONE launch per stage: the layer inputs travel as a
+ * host array of device pointers (kernel arguments, at most BH_BN_MAX_LAYERS), their geometry in a device table. */
+#define BH_BN_MAX_LAYERS 448
+#define BH_BN_TILE 4096 /* elements per backward work item */
 
-/* Per-channel sum and sum of squares of x[B,C,HW] over (b, hw), split in S = bh_bnstat_slabs(...) slabs per channel:
- * sums_dev[C * S * 2] doubles (overwritten).  Returns S (> 0) or a negative error.
+typedef struct bh_bn_layer { /* 64 bytes, device resident, built once per attack by bh_bn_plan_build */
+  int64_t flat_off;      /* element offset of the layer inside the packed gradient buffer (multiple of 4) */
+  int64_t sums_off;      /* offset, in (sum, sum of squares) pairs, of its C x S partial sums */
+  int32_t chan_off;      /* offset of its channels in the packed running statistics / coefficient arrays */
+  int32_t B, C, HW;      /* x_l is [B, C, HW] contiguous fp32 (NCHW); 16-byte aligned when HW % 4 == 0 */
+  int32_t S;             /* forward slabs per channel */
+  int32_t narrow;        /* 1: B*HW is small, one wavefront per channel in the forward pass */
+  float weight;          /* weight_l */
+  uint32_t div_unit_mul, div_unit_shr; /* fast division by HW/4 (HW % 4 == 0) or HW */
+  uint32_t div_c_mul, div_c_shr;       /* fast division by C */
+  int32_t reserved;
+} bh_bn_layer;
+
+typedef struct bh_bn_item { /* 16 bytes: forward (layer, channel [first of 4 when narrow], slab, -); */
+  int32_t layer, a, b, c;   /*           backward (layer, first unit, units, -), unit = float4 or float */
+} bh_bn_item;
+
+/* Host arithmetic: table sizes for layers of shape [B[l], C[l], HW[l]]. */
+int bh_bn_plan_size(int32_t n_layers, const int32_t* B, const int32_t* C, const int32_t* HW, int64_t* n_fwd_items,
+                    int64_t* n_bwd_items, int64_t* flat_elems, int64_t* n_sum_pairs, int64_t* n_channels);
+/* Host arithmetic: fill the three tables (host memory; the caller uploads them once).  `weights` may be NULL (= 1). */
+int bh_bn_plan_build(int32_t n_layers, const int32_t* B, const int32_t* C, const int32_t* HW, const float* weights,
+                     bh_bn_layer* layers, bh_bn_item* fwd_items, int64_t n_fwd_items, bh_bn_item* bwd_items,
+                     int64_t n_bwd_items);
+
+/* Stage 1: per-channel sum and sum of squares of every layer, one workgroup per forward item, into
+ * sums_dev[2 * n_sum_pairs] doubles (overwritten).  `x_ptrs` / `hw_host`: HOST arrays (device pointers, HW per layer).
  * reference: deepinversion.py:93-96 (mean / biased var of the BN input). */
-int bh_bnstat_sums(const float* x, int32_t B, int32_t C, int64_t HW, double* sums_dev, void* stream);
+int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
+               const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, void* stream);
 
-/* From the sums: mean_c, var_c (biased) and r = |running_var - var|_2 + |running_mean - mean|_2 -> value_dev[0]
- * (fp32); also the backward coefficients coef_dev[2*C] (fp32): dr/dx[b,c,hw] = A_c + B_c * x[b,c,hw].
- * reference: deepinversion.py:96-101. */
-int bh_bnstat_finalize(const double* sums_dev, int32_t B, int32_t C, int64_t HW, const float* running_mean,
-                       const float* running_var, float* value_dev, float* coef_dev, double* scratch_dev /* [2*C] */,
-                       void* stream);
+/* Stage 2 (one workgroup per layer): mean_c, var_c, r_l, the backward coefficients coef_dev[2 * n_channels] (fp32,
+ * 8-byte aligned; d total / d x_l[b,c,hw] = A_c + B_c * x) and total_dev[0] = sum_l weight_l * r_l, added up in layer
+ * order by the last workgroup to finish.  `running_mean` / `running_var`: packed per chan_off.  `layer_values_dev`:
+ * n_layers doubles of workspace; `counter_dev`: a zeroed uint32 (re-zeroed by the kernel).
+ * reference: deepinversion.py:96-101, regularizers.py:222-227. */
+int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double* sums_dev, const float* running_mean,
+                   const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
+                   void* counter_dev, void* stream);
 
-/* grad_x = gout * (A_c + B_c * x); gout read from *gout_dev.  grad_x is overwritten. */
-int bh_bnstat_bwd(const float* x, int32_t B, int32_t C, int64_t HW, const float* coef_dev, const float* gout_dev,
-                  float* grad_x, void* stream);
+/* Backward of all layers in one launch: grad_flat[flat_off_l + i] = gout * (A_c + B_c * x_l[i]); gout read from
+ * *gout_dev (NULL = 1).  grad_flat (16-byte aligned, flat_elems floats) is overwritten. */
+int bh_bn_bwd(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
+              const bh_bn_item* bwd_items_dev, int64_t n_bwd_items, const float* coef_dev, const float* gout_dev,
+              float* grad_flat, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Trial state, loss commit and the fused candidate step ("kernel B")
@@ -226,7 +285,7 @@ typedef struct bh_step_params {
   double beta1, beta2, eps; /* doubles: torch derives 1-beta in double before rounding to fp32 (1 - 0.999f is 1.3e-5 off) */
   int32_t decoupled_wd; /* AdamW: x *= sched[2] first                      common.py:10-12 */
   float langevin;       /* langevin_noise (0 = off); noise must be non-NULL when > 0   :167-170 */
-  float grad_clip;      /* <= 0 = off; uses state[BH_STATE_GNORM]                       :171-174 */
+  float grad_clip;      /* < 0 = off (0 is a legal threshold); uses state[BH_STATE_GNORM] :171-174 */
 } bh_step_params;
 
 /* One fused elementwise pass: assemble the gradient (g + g_reg + langevin*lr*noise), clip, sign, Adam/AdamW moment

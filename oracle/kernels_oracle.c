@@ -175,7 +175,7 @@ double oracle_bnstat(const float* x, int B, int C, int64_t HW, const float* rm, 
 /*
  * One candidate step: gradient post-processing (optimization_based_attack.py:167-184), torch.optim Adam / AdamW
  * single-tensor update (selected at auxiliaries/common.py:5-12) and box projection (:117-118).
- * sign_mode 0 none / 1 hard / 2 soft; step is 1-based; noise may be NULL; clip <= 0 disables clipping.
+ * sign_mode 0 none / 1 hard / 2 soft; step is 1-based; noise may be NULL; clip < 0 disables clipping (0 is a legal threshold).
  * All state updated in place (fp64 copies of fp32 state supplied by the test).
  */
 void oracle_candidate_step(int64_t n, int64_t plane, int channels, double* x, const double* g_in, const double* noise,
@@ -188,7 +188,7 @@ void oracle_candidate_step(int64_t n, int64_t plane, int channels, double* x, co
     nrm += g * g;
   }
   nrm = sqrt(nrm);
-  double clip_mul = (clip > 0 && nrm > clip) ? clip / (nrm + 1e-6) : 1.0;
+  double clip_mul = (clip >= 0 && nrm > clip) ? clip / (nrm + 1e-6) : 1.0;
   double soft = 1.0 - (double)iteration / (double)max_iterations;
   double bc1 = 1 - pow(beta1, step), bc2 = 1 - pow(beta2, step);
   for (int64_t i = 0; i < n; ++i) {

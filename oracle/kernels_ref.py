@@ -98,7 +98,7 @@ def bnstat(x, running_mean, running_var):
 
 
 def candidate_step(x, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False, sign_mode=0,
-                   iteration=0, max_iterations=1, noise=None, langevin=0.0, clip=0.0, boxed=False, lo=None, hi=None,
+                   iteration=0, max_iterations=1, noise=None, langevin=0.0, clip=-1.0, boxed=False, lo=None, hi=None,
                    plane=1, channels=1):
     """Returns updated fp64 copies (x, m, v)."""
     lib = load_oracle()

@@ -42,15 +42,33 @@ def gm_case(name, shapes):
         kind = _lib.GM_KINDS[kind_name]
         weights = torch.linspace(1, 0.1, len(shapes), device=dev) if kind_name == "tag-euclidean" else None
         plan.enable_timing()
+        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         for _ in range(30):
-            stats = plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights)
+            stats = plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights, ticket=ticket)
             plan.backward(kind, rec, stats, None, weights)
         t = plan.drain_timers()
         fwd = sorted(t["fwd"])[5:]
         bwd = sorted(t["bwd"])[5:]
         f, b = sum(fwd) / len(fwd), sum(bwd) / len(bwd)
         res[kind_name] = dict(fwd_us=round(f, 2), fwd_GBs=round(2 * n * 4 / f / 1e3, 1), bwd_us=round(b, 2), bwd_GBs=round(3 * n * 4 / b / 1e3, 1))
-    res.update(tensors=len(shapes), elements=n, chunks=plan.n_chunks)
+    res.update(tensors=len(shapes), elements=n, chunks=plan.n_chunks, rows=plan.n_rows)
+    # forward stage (reduction + objective epilogue) under the knobs: rows cap x fused / two-launch finalize.
+    # events: dispatch begin -> end of the forward launch(es) alone; burst: back-to-back stage time incl. the epilogue launch
+    sweep = {}
+    for cap in (512, 1024, 1536, 2048):
+        lib.bh_gm_set_rows_cap(cap)
+        p2 = GradientMatchPlan(data)
+        for fused in (True, False):
+            ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+            p2.enable_timing()
+            for _ in range(30):
+                p2.forward(0, rec, 1.0, 0.0, 1e-7, None, ticket=ticket, fused=fused)
+            ev = sorted(p2.drain_timers()["fwd"])[5:]
+            us = burst(lambda: p2.forward(0, rec, 1.0, 0.0, 1e-7, None, ticket=ticket, fused=fused), reps=40)
+            sweep[f"cap{cap}_{'fused' if fused else 'twolaunch'}"] = dict(rows=p2.n_rows, fwd_event_us=round(sum(ev) / len(ev), 2),
+                                                                         stage_burst_us=round(us, 2))
+    lib.bh_gm_set_rows_cap(2048)
+    res["forward_stage_sweep_cosine"] = sweep
     out[f"kernelA_{name}"] = res
 
 
@@ -103,32 +121,35 @@ with torch.no_grad():
 for h in hs:
     h.remove()
 total = sum(a.numel() for a in acts)
-bufs = []
-for a in acts:
-    B_, C = a.shape[0], a.shape[1]
-    HW = a.numel() // (B_ * C)
-    S = lib.bh_bnstat_slabs(B_, C, HW)
-    bufs.append(dict(x=a.contiguous(), B=B_, C=C, HW=HW, sums=torch.empty(C * S * 2, dtype=torch.float64, device=dev),
-                     scratch=torch.empty(2 * C, dtype=torch.float64, device=dev), out=torch.empty(1 + 2 * C, device=dev),
-                     rm=torch.zeros(C, device=dev), rv=torch.ones(C, device=dev), grad=torch.empty_like(a)))
+from breaching_amd.priors import BnStatPlan
+bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+acts = [a.contiguous() for a in acts]
+plan = BnStatPlan([a.shape for a in acts], [m.running_mean for m in bns], [m.running_var for m in bns], [1.0] * len(acts), dev)
+sums = torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=dev)
+layer_values = torch.empty(plan.n_layers, dtype=torch.float64, device=dev)
+coef = torch.empty(2 * plan.n_channels, device=dev)
+total_out = torch.empty(1, device=dev)
+ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+grad_flat = torch.empty(plan.flat_elems, device=dev)
+ptrs = plan.pointers(acts)
+def d_sums():
+    _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev), plan.n_fwd,
+                              _lib.ptr(sums), _lib.current_stream_handle(dev)), "sums")
+def d_fin():
+    _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
+                                  _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total_out),
+                                  _lib.ptr(ticket), _lib.current_stream_handle(dev)), "finalize")
 def d_fwd():
-    st = _lib.current_stream_handle(dev)  # the capture stream while a graph is being recorded
-    for b in bufs:
-        lib.bh_bnstat_sums(_lib.ptr(b["x"]), b["B"], b["C"], b["HW"], _lib.ptr(b["sums"]), st)
-        lib.bh_bnstat_finalize(_lib.ptr(b["sums"]), b["B"], b["C"], b["HW"], _lib.ptr(b["rm"]), _lib.ptr(b["rv"]), _lib.ptr(b["out"]),
-                               ctypes_offset(b["out"], 1), _lib.ptr(b["scratch"]), st)
+    d_sums(); d_fin()
 def d_bwd():
-    st = _lib.current_stream_handle(dev)
-    for b in bufs:
-        lib.bh_bnstat_bwd(_lib.ptr(b["x"]), b["B"], b["C"], b["HW"], ctypes_offset(b["out"], 1), None, _lib.ptr(b["grad"]), st)
-def graphed(fn):
-    fn(); torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        fn()
-    return g.replay
-us_f, us_b = burst(graphed(d_fwd), reps=10, warm=2), burst(graphed(d_bwd), reps=10, warm=2)
-out["kernelD_resnet50_B8"] = dict(layers=len(acts), elements=total, fwd_us=round(us_f, 1), fwd_GBs=round(total * 4 / us_f / 1e3, 1),
+    _lib.check(lib.bh_bn_bwd(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.bwd_dev), plan.n_bwd,
+                             _lib.ptr(coef), None, _lib.ptr(grad_flat), _lib.current_stream_handle(dev)), "bwd")
+us_s, us_fin = burst(d_sums, reps=20, warm=3), burst(d_fin, reps=20, warm=3)
+us_f, us_b = burst(d_fwd, reps=20, warm=3), burst(d_bwd, reps=20, warm=3)
+out["kernelD_resnet50_B8"] = dict(layers=len(acts), elements=total, fwd_items=plan.n_fwd, bwd_items=plan.n_bwd,
+                                  sums_us=round(us_s, 1), finalize_us=round(us_fin, 1),
+                                  fwd_us=round(us_f, 1), fwd_GBs=round(total * 4 / us_f / 1e3, 1),
                                   bwd_us=round(us_b, 1), bwd_GBs=round(2 * total * 4 / us_b / 1e3, 1),
-                                  note="53 x (sums + finalize) launches forward, 53 launches backward, replayed from a hipGraph")
+                                  note="one sums launch + one finalize launch forward, one launch backward for all 53 layers "
+                                       "(burst of back-to-back launches; 355.6 MB read forward, read + written backward)")
 print(json.dumps(out, indent=1))

@@ -18,8 +18,8 @@ def _declared_functions():
 
 def test_header_declares_the_expected_surface():
     names = _declared_functions()
-    for required in ("bh_gm_fwd", "bh_gm_bwd", "bh_gm_finalize", "bh_gm_pack", "bh_prior_tv_norm", "bh_bnstat_sums",
-                     "bh_bnstat_finalize", "bh_bnstat_bwd", "bh_loss_commit", "bh_candidate_step", "bh_grad_norm",
+    for required in ("bh_gm_fwd", "bh_gm_bwd", "bh_gm_finalize", "bh_gm_pack", "bh_prior_tv_norm", "bh_bn_sums",
+                     "bh_bn_finalize", "bh_bn_bwd", "bh_bn_plan_build", "bh_gm_fwd_rows", "bh_loss_commit", "bh_candidate_step", "bh_grad_norm",
                      "bh_state_reset", "bh_abi_version"):
         assert required in names
 
@@ -85,7 +85,7 @@ def test_chunk_table_host_helpers(hip_lib):
     assert list(bounds) == [0, _lib.BH_GM_MAX_PTRS, len(many)]
     # invalid arguments are reported, not crashed on
     assert hip_lib.bh_gm_table_size(-1, arr, byref(n_chunks), byref(flat)) == -1
-    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, None, None, None) == -1
+    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, None, None, None, None) == -1
     assert hip_lib.bh_candidate_step(None, None, None, None, None, None, None, None, None, None, None) == -1
 
 
@@ -119,23 +119,77 @@ def test_header_is_valid_c99(tmp_path):
     assert proc.returncode == 0, proc.stderr
 
 
-def test_step_params_layout_matches_ctypes(tmp_path):
-    """sizeof / offsetof of bh_step_params as the C compiler sees them == the ctypes mirror in _lib.StepParams."""
+@pytest.mark.parametrize("c_name,mirror", [("bh_step_params", "StepParams"), ("bh_gm_fused", "GmFused"), ("bh_gm_chunk", "GmChunk"),
+                                           ("bh_bn_layer", "BnLayer"), ("bh_bn_item", "BnItem")])
+def test_struct_layouts_match_ctypes(tmp_path, c_name, mirror):
+    """sizeof / offsetof of every ABI struct as the C compiler sees them == its ctypes mirror in _lib."""
     import subprocess
 
     from breaching_amd import _lib
 
-    fields = [name for name, _ in _lib.StepParams._fields_]
-    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "breach_hip.h"\nint main(void) {\n printf("%zu", sizeof(bh_step_params));\n'
-    prog += "".join(f' printf(" %zu", offsetof(bh_step_params, {f}));\n' for f in fields)
+    cls = getattr(_lib, mirror)
+    fields = [name for name, _ in cls._fields_]
+    prog = f'#include <stdio.h>\n#include <stddef.h>\n#include "breach_hip.h"\nint main(void) {{\n printf("%zu", sizeof({c_name}));\n'
+    prog += "".join(f' printf(" %zu", offsetof({c_name}, {f}));\n' for f in fields)
     prog += " return 0; }\n"
     src, exe = tmp_path / "layout.c", tmp_path / "layout"
     src.write_text(prog)
     subprocess.run(["gcc", "-std=c99", f"-I{os.path.join(ROOT, 'include')}", str(src), "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
-    assert int(out[0]) == ctypes.sizeof(_lib.StepParams)
+    assert int(out[0]) == ctypes.sizeof(cls)
     for name, off in zip(fields, out[1:]):
-        assert int(off) == getattr(_lib.StepParams, name).offset, name
+        assert int(off) == getattr(cls, name).offset, name
+
+
+def test_bn_plan_host_tables(hip_lib):
+    """Host arithmetic of kernel D's plan: every element of every layer is covered exactly once by the backward items, every
+    (channel, slab) pair by the forward items, and the fast-division constants divide exactly over their whole range."""
+    from ctypes import byref, c_float, c_int32, c_int64
+
+    from breaching_amd import _lib
+
+    shapes = [(8, 64, 112 * 112), (8, 256, 56 * 56), (8, 512, 28 * 28), (8, 1024, 14 * 14), (8, 2048, 7 * 7), (1, 3, 25), (2, 5, 4097)]
+    n = len(shapes)
+    B, C, HW = [(c_int32 * n)(*[s[k] for s in shapes]) for k in range(3)]
+    sizes = [c_int64() for _ in range(5)]
+    assert hip_lib.bh_bn_plan_size(n, B, C, HW, *[byref(v) for v in sizes]) == 0
+    n_fwd, n_bwd, flat, pairs, chans = [v.value for v in sizes]
+    assert chans == sum(s[1] for s in shapes) and flat == sum((s[0] * s[1] * s[2] + 3) // 4 * 4 for s in shapes)
+    layers, fwd, bwd = (_lib.BnLayer * n)(), (_lib.BnItem * n_fwd)(), (_lib.BnItem * n_bwd)()
+    w = (c_float * n)(*[1.0 + i for i in range(n)])
+    assert hip_lib.bh_bn_plan_build(n, B, C, HW, w, layers, fwd, n_fwd, bwd, n_bwd) == 0
+    assert hip_lib.bh_bn_plan_build(n, B, C, HW, w, layers, fwd, n_fwd - 1, bwd, n_bwd) == -1
+    seen_pairs = set()
+    for it in fwd:
+        L = layers[it.layer]
+        if L.narrow:
+            assert L.S == 1 and it.b == 0 and it.a % 4 == 0
+            for c in range(it.a, min(it.a + 4, L.C)):
+                seen_pairs.add((it.layer, c, 0))
+        else:
+            assert 0 <= it.a < L.C and 0 <= it.b < L.S
+            seen_pairs.add((it.layer, it.a, it.b))
+    assert len(seen_pairs) == pairs == sum(layers[l].C * layers[l].S for l in range(n))
+    covered = [0] * n
+    for it in bwd:
+        assert it.a == covered[it.layer] and 0 < it.b <= (1024 if layers[it.layer].HW % 4 == 0 else 4096)
+        covered[it.layer] += it.b
+    for l, (b, c, hw) in enumerate(shapes):
+        L = layers[l]
+        unit = hw // 4 if hw % 4 == 0 else hw
+        assert covered[l] * (4 if hw % 4 == 0 else 1) == b * c * hw
+        assert (L.B, L.C, L.HW, L.weight) == (b, c, hw, 1.0 + l) and L.flat_off % 4 == 0
+        assert bool(L.narrow) == (b * hw < 2048)
+        for d, mul, shr in ((unit, L.div_unit_mul, L.div_unit_shr), (c, L.div_c_mul, L.div_c_shr)):
+            top = b * c * unit
+            for v in {0, 1, d - 1, d, d + 1, 2 * d - 1, top - 1, top // 2, (1 << 31) - 1} | set(range(max(top - 3 * d, 0), top, max(d // 3, 1))):
+                if 0 <= v < (1 << 31):
+                    q = v if d == 1 else ((v * mul) >> 32) >> shr
+                    assert q == v // d, (l, d, v)
+    # layer count beyond the pointer block, degenerate shapes
+    assert hip_lib.bh_bn_plan_size(0, B, C, HW, *[byref(v) for v in sizes]) == -1
+    bad = (c_int32 * n)(*([0] + [s[1] for s in shapes[1:]]))
+    assert hip_lib.bh_bn_plan_size(n, B, bad, HW, *[byref(v) for v in sizes]) == -1
 
 
 def test_no_compatibility_layers_in_the_product():

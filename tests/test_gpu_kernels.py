@@ -193,13 +193,13 @@ def test_tv_norm_matches_c_oracle(shape, opp, kernels_oracle, hip_lib):
 
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib):
-    from breaching_amd.priors import _BnStatFunction
+    from breaching_amd.priors import bn_statistic
 
     gold = np.load(os.path.join(golden_dir, "kernels.npz"))
     x = torch.tensor(gold[f"bn_{tag}__x"], device=_dev(), requires_grad=True)
     rm = torch.tensor(gold[f"bn_{tag}__rm"], device=_dev())
     rv = torch.tensor(gold[f"bn_{tag}__rv"], device=_dev())
-    value = _BnStatFunction.apply(x, rm, rv)
+    value = bn_statistic(x, rm, rv)
     (g,) = torch.autograd.grad(value, x)
     want = float(gold[f"bn_{tag}__value"][0])
     assert abs(value.item() - want) <= 5e-6 * abs(want)
@@ -208,7 +208,7 @@ def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib):
 
 @pytest.mark.parametrize("shape", [(8, 64, 112, 112), (8, 2048, 7, 7), (2, 256, 14, 14), (1, 3, 5, 5)])
 def test_bnstat_matches_c_oracle(shape, kernels_oracle, hip_lib):
-    from breaching_amd.priors import _BnStatFunction
+    from breaching_amd.priors import bn_statistic
     from oracle import kernels_ref
 
     rng = np.random.default_rng(13)
@@ -221,7 +221,7 @@ def test_bnstat_matches_c_oracle(shape, kernels_oracle, hip_lib):
     rm = rng.standard_normal(C).astype(np.float32) * 0.1
     rv = (rng.random(C).astype(np.float32) + 0.5)
     x = torch.tensor(x_np, device=_dev(), requires_grad=True)
-    value = _BnStatFunction.apply(x, torch.tensor(rm, device=_dev()), torch.tensor(rv, device=_dev()))
+    value = bn_statistic(x, torch.tensor(rm, device=_dev()), torch.tensor(rv, device=_dev()))
     (g,) = torch.autograd.grad(value * 1.5, x)
     want_v, want_g, _, _ = kernels_ref.bnstat(x_np, rm, rv)
     assert abs(value.item() - want_v) <= 2e-6 * abs(want_v)
@@ -260,14 +260,14 @@ def _step_once(hip_lib, n_shape, sign_mode, boxed, decoupled, langevin, clip, st
     best_o = xo.copy()
     min_o, dead = float("inf"), False
     for it in range(steps):
-        g_np = rng.standard_normal(n).astype(np.float32) * (10.0 if clip > 0 else 1.0)
+        g_np = rng.standard_normal(n).astype(np.float32) * (10.0 if clip >= 0 else 1.0)
         greg_np = rng.standard_normal(n).astype(np.float32) * 0.1
         noise_np = rng.standard_normal(n).astype(np.float32) if langevin > 0 else None
         g, greg = torch.tensor(g_np, device=dev), torch.tensor(greg_np, device=dev)
         noise = torch.tensor(noise_np, device=dev) if noise_np is not None else None
         loss = torch.tensor([losses[it]], dtype=torch.float32, device=dev)
         _lib.check(hip_lib.bh_loss_commit(_lib.ptr(state), _lib.ptr(history), soft_max_it, _lib.ptr(loss), None, 0, None, None, stream), "commit")
-        if clip > 0:
+        if clip >= 0:
             _lib.check(hip_lib.bh_grad_norm(_lib.ptr(state), _lib.ptr(g), _lib.ptr(greg), _lib.ptr(noise), n, _lib.ptr(sched), langevin, _lib.ptr(ws), stream), "norm")
         _lib.check(hip_lib.bh_candidate_step(_lib.ptr(state), _lib.ptr(sched), P, _lib.ptr(x), _lib.ptr(g), _lib.ptr(greg), _lib.ptr(noise),
                                              _lib.ptr(m), _lib.ptr(v), _lib.ptr(best), stream), "step")
@@ -286,10 +286,11 @@ def _step_once(hip_lib, n_shape, sign_mode, boxed, decoupled, langevin, clip, st
 
 
 @pytest.mark.parametrize("sign_mode,boxed,decoupled,langevin,clip", [
-    (1, True, False, 0.0, 0.0),   # invertinggradients: hard sign, boxed Adam
-    (0, True, False, 0.01, 0.0),  # see-through: Langevin noise
-    (0, False, True, 0.0, 1.0),   # TAG: AdamW + clipping
-    (2, True, False, 0.0, 0.0),   # modern: soft sign
+    (1, True, False, 0.0, -1.0),   # invertinggradients: hard sign, boxed Adam
+    (0, True, False, 0.01, -1.0),  # see-through: Langevin noise
+    (0, False, True, 0.0, 1.0),    # TAG: AdamW + clipping
+    (2, True, False, 0.0, -1.0),   # modern: soft sign
+    (0, False, False, 0.0, 0.0),   # grad_clip = 0 is a threshold, not "off": the gradient is scaled to ~0 (:171-174)
 ])
 def test_candidate_step_matches_c_oracle(sign_mode, boxed, decoupled, langevin, clip, kernels_oracle, hip_lib):
     r = _step_once(hip_lib, (2, 3, 9, 7), sign_mode, boxed, decoupled, langevin, clip, steps=6)
@@ -307,9 +308,116 @@ def test_candidate_step_matches_c_oracle(sign_mode, boxed, decoupled, langevin, 
 
 
 def test_candidate_step_best_copy_is_post_step_candidate(kernels_oracle, hip_lib):
-    r = _step_once(hip_lib, (1, 3, 8, 8), 1, True, False, 0.0, 0.0, steps=4)
+    r = _step_once(hip_lib, (1, 3, 8, 8), 1, True, False, 0.0, -1.0, steps=4)
     # losses 3, 2, 2.5, 1 -> improvements at iterations 0, 1, 3 -> best == candidate after the 4th step
     np.testing.assert_array_equal(r["best"], r["x"])
-    r = _step_once(hip_lib, (1, 3, 8, 8), 1, True, False, 0.0, 0.0, steps=3)
+    r = _step_once(hip_lib, (1, 3, 8, 8), 1, True, False, 0.0, -1.0, steps=3)
     assert not np.array_equal(r["best"], r["x"])  # iteration 2 (loss 2.5) did not improve
     np.testing.assert_allclose(r["best"], r["best_o"], rtol=2e-5, atol=2e-6)
+
+
+def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_lib):
+    """Kernel D over a whole model's BatchNorm inputs at once: wide (whole workgroup per channel slab), narrow (one wavefront
+    per channel), vectorised and scalar (H*W % 4 != 0) layers mixed; total = sum_l w_l * r_l and every layer's gradient."""
+    from breaching_amd.priors import BnStatPlan, _BnStatFunction
+    from oracle import kernels_ref
+
+    rng = np.random.default_rng(29)
+    shapes = [(4, 16, 56, 56), (4, 32, 28, 28), (4, 70, 7, 7), (4, 5, 14, 14), (4, 3, 33, 31), (4, 9, 1, 1), (2, 6, 96, 96)]
+    weights = [3.0, 1.0, 0.5, 1.0, 2.0, 1.0, 0.25]
+    xs_np = [rng.standard_normal(s).astype(np.float32) * (1 + i) + 0.1 * i for i, s in enumerate(shapes)]
+    rms = [rng.standard_normal(s[1]).astype(np.float32) * 0.2 for s in shapes]
+    rvs = [rng.random(s[1]).astype(np.float32) + 0.5 for s in shapes]
+    xs = [torch.tensor(x, device=_dev(), requires_grad=True) for x in xs_np]
+    plan = BnStatPlan([x.shape for x in xs], [torch.tensor(m, device=_dev()) for m in rms],
+                      [torch.tensor(v, device=_dev()) for v in rvs], weights, _dev())
+    ticket = torch.zeros(1, dtype=torch.int32, device=_dev())
+    for _ in range(2):  # the ticket word is re-zeroed by the kernel: the second call must work like the first
+        total = _BnStatFunction.apply(plan, ticket, *xs)
+        grads = torch.autograd.grad(total * 0.7, xs)
+        want_total, want_grads = 0.0, []
+        for x, m, v, w in zip(xs_np, rms, rvs, weights):
+            value, grad, _, _ = kernels_ref.bnstat(x, m, v)
+            want_total += w * value
+            want_grads.append(0.7 * w * grad)
+        assert abs(total.item() - want_total) <= 2e-6 * abs(want_total)
+        for g, wg in zip(grads, want_grads):
+            _assert_grads([g.cpu().numpy()], [wg], rtol=1e-5)
+    assert int(ticket.item()) == 0
+
+
+def test_gm_forward_fused_and_two_launch_finalize_agree(hip_lib):
+    """Forward + epilogue as one launch (last workgroup finishes) == forward launch + stand-alone finalize, bit for bit;
+    the persistent-grid size (rows cap) only changes the fp64 summation order."""
+    from breaching_amd import _lib
+    from breaching_amd.gm import GradientMatchPlan
+
+    rng = np.random.default_rng(5)
+    shapes = [(300_000,), (17,), (4096 * 3,), (70_001,), (5,)] + [(1000 + 7 * i,) for i in range(460)]  # two launch groups
+    data = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
+    rec = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
+    results = {}
+    try:
+        for cap in (2048, 64, 3):
+            assert hip_lib.bh_gm_set_rows_cap(cap) == 0
+            plan = GradientMatchPlan(data)
+            assert plan.n_rows <= 2 * cap
+            ticket = torch.zeros(1, dtype=torch.int32, device=_dev())
+            for kind in (0, 4, 6):
+                w = torch.linspace(1.0, 0.1, len(shapes), device=_dev()) if kind == 6 else None
+                fused = [plan.forward(kind, rec, 1.5, 0.1, 1e-7, w, ticket=ticket, fused=True).cpu() for _ in range(2)]
+                plain = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w, fused=False).cpu()
+                assert torch.equal(fused[0][:6], plain[:6]) and torch.equal(fused[1][:6], plain[:6])
+                results[(cap, kind)] = plain[:6].double().numpy()
+            assert int(ticket.item()) == 0
+    finally:
+        hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_MAX_ROWS)
+    assert hip_lib.bh_gm_set_rows_cap(0) == -1 and hip_lib.bh_gm_set_rows_cap(4096) == -1
+    for kind in (0, 4, 6):
+        for cap in (64, 3):
+            np.testing.assert_allclose(results[(cap, kind)], results[(2048, kind)], rtol=2e-6)
+
+
+def test_plan_is_never_reused_for_another_gradient_list(hip_lib):
+    """One attacker, user after user (benchmark_breaches.py:60-70): the second user's gradients may land on the addresses the
+    first user's were freed from.  The packed copy must follow the tensors, not their addresses; in-place edits count too."""
+    from breaching_amd.gm import HipEuclidean
+
+    shapes = [(5000,), (33, 7), (4096,)]
+    gen = torch.Generator().manual_seed(0)
+    rec = [torch.randn(s, generator=gen).to(_dev()).requires_grad_(True) for s in shapes]
+    obj = HipEuclidean(scale=1.0)
+    obj.initialize(None, type("I", (), dict(mixed_precision=False))(), None)
+
+    def loss_for(data):
+        return obj.gradient_based_loss(rec, data).item()
+
+    first = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
+    ptrs = [t.data_ptr() for t in first]
+    want_first = sum(0.5 * float(((r.detach() - d) ** 2).sum()) for r, d in zip(rec, first))
+    assert loss_for(first) == pytest.approx(want_first, rel=1e-5)
+    assert len(obj._plans) == 1
+    del first
+    second = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]  # the caching allocator hands the same blocks back
+    reused = [t.data_ptr() for t in second] == ptrs
+    want_second = sum(0.5 * float(((r.detach() - d) ** 2).sum()) for r, d in zip(rec, second))
+    assert abs(want_second - want_first) > 1e-3 * want_first
+    assert loss_for(second) == pytest.approx(want_second, rel=1e-5), f"stale packed gradients (addresses reused: {reused})"
+    # in-place edit of the observed list (e.g. base_attack.py:298-303 normalisation after a first evaluation)
+    second[0].mul_(2.0)
+    want_edited = sum(0.5 * float(((r.detach() - d) ** 2).sum()) for r, d in zip(rec, second))
+    assert loss_for(second) == pytest.approx(want_edited, rel=1e-5)
+    # two lists alternating (multi-query payloads): one plan each, none rebuilt
+    third = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
+    n_before = len(obj._plans)
+    for _ in range(3):
+        loss_for(second), loss_for(third)
+    assert len(obj._plans) == n_before + 1
+    # non-contiguous observed gradient: compared in logical order
+    base = torch.randn(7, 33, generator=gen).to(_dev())
+    strided = [second[0], base.t(), second[2]]
+    assert not strided[1].is_contiguous()
+    want_strided = sum(0.5 * float(((r.detach() - d) ** 2).sum()) for r, d in zip(rec, strided))
+    assert loss_for(strided) == pytest.approx(want_strided, rel=1e-5)
+    obj.initialize(None, type("I", (), dict(mixed_precision=False))(), None)
+    assert obj._plans == []
