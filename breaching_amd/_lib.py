@@ -15,6 +15,7 @@ BH_GM_CHUNK = 4096
 BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
 BH_GM_MAX_ROWS = 2048
+BH_GM_DEFAULT_ROWS = 512
 BH_GM_STAT_WORDS = 8
 BH_PRIOR_MAX_GRID = 1024
 BH_BN_MAX_LAYERS = 448
@@ -38,11 +39,6 @@ SIGN_NONE, SIGN_HARD, SIGN_SOFT = 0, 1, 2
 
 class GmChunk(Structure):
     _fields_ = [("flat_off", c_int64), ("tensor_off", c_int64), ("tensor", c_int32), ("len", c_int32)]
-
-
-class GmFused(Structure):
-    _fields_ = [("counter_dev", c_void_p), ("stats_dev", c_void_p), ("span_accum_dev", c_void_p), ("scale", c_float),
-                ("fudge", c_float)]
 
 
 class BnLayer(Structure):
@@ -85,7 +81,7 @@ _PROTOTYPES = {
     "bh_gm_fwd": (
         c_int,
         [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p,
-         POINTER(GmFused), c_void_p, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_void_p],
     ),
     "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32)]),
     "bh_gm_set_rows_cap": (c_int32, [c_int32]),

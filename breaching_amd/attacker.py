@@ -21,7 +21,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from . import _lib, schedules, trials
+from . import _lib, schedules, trials, workers
 from .gm import objective_lookup
 from .priors import HipNormRegularization, HipTotalVariation, launch_tv_norm, regularizer_lookup
 
@@ -111,8 +111,15 @@ class HipOptimizationAttacker:
     # reconstruct
     # ==============================================================================================================
     def reconstruct(self, server_payload, shared_data, server_secrets=None, initial_data=None, dryrun=False):
-        rec_models, labels, stats = self.prepare_attack(server_payload, shared_data)
         num_trials = self.cfg.restarts.num_trials
+        preset = getattr(self, "_preset", None)  # a trial worker: starting points and labels come from rank 0
+        pool = self._trial_worker_pool(num_trials) if preset is None else None
+        if pool is not None:  # host copies of the caller's inputs, taken before prepare_attack rebinds / normalises them
+            job_inputs = dict(server_payload=workers.to_cpu(list(server_payload)), shared_data=workers.to_cpu(list(shared_data)),
+                              server_secrets=workers.to_cpu(server_secrets), initial_data=workers.to_cpu(initial_data), dryrun=dryrun)
+        rec_models, labels, stats = self.prepare_attack(server_payload, shared_data)
+        if preset is not None and preset["labels"] is not None:
+            labels = preset["labels"].to(self.setup["device"])
         shard = trials.TrialShard.current(num_trials)
         num_points = shared_data[0]["metadata"]["num_data_points"]
         # Device RNG order.  The reference draws trial t's starting point right before trial t runs, and its Langevin
@@ -122,7 +129,14 @@ class HipOptimizationAttacker:
         # one at a time and each draws its start when its turn comes.  Only noise + several ranks deviates (documented).
         noisy = float(self.cfg.optim.langevin_noise or 0.0) > 0
         lazy_draws = noisy and shard.world == 1
-        inits = {} if lazy_draws else {t: self._draw_initial_state(num_points, labels) for t in range(num_trials)}
+        if preset is not None:
+            inits = {t: self._adopt_initial_state(state) for t, state in preset["inits"].items()}
+        else:
+            inits = {} if lazy_draws else {t: self._draw_initial_state(num_points, labels) for t in range(num_trials)}
+        if pool is not None:  # rank r gets the starting points of its trials, drawn here in the reference's order
+            pool.submit([dict(job_inputs, labels=workers.to_cpu(labels),
+                              inits={t: workers.to_cpu(tuple(inits[t])) for t in range(r, num_trials, pool.world)})
+                         for r in range(1, pool.world)])
 
         local_scores, local_solutions = {}, {}
         mine = list(shard.local_trials())
@@ -142,7 +156,15 @@ class HipOptimizationAttacker:
                                                             self._score_labels(solution, labels), rec_models, shared_data)
         except KeyboardInterrupt:
             print("Trial procedure manually interruped.")
+        if pool is not None:
+            pool.expect("trials_done")  # a crashed worker raises here instead of hanging the selection collective
+            pool.broadcast(("go",))
+        before_select = getattr(self, "_before_select", None)
+        if before_select is not None:
+            before_select()
         optimal = self._select_optimal_reconstruction(local_solutions, local_scores, stats, shard)
+        if pool is not None:
+            pool.expect("ok")
         reconstructed_data = self._package(optimal, labels)
         if server_payload[0]["metadata"].modality == "text":
             raw = reconstructed_data["data"]
@@ -155,6 +177,44 @@ class HipOptimizationAttacker:
             reconstructed_data["data"] = full
             reconstructed_data["labels"] = server_secrets["ClassAttack"]["all_labels"]
         return reconstructed_data, stats
+
+    # trial workers --------------------------------------------------------------------------
+    def _trial_worker_pool(self, num_trials):
+        """The pool of per-GPU worker processes that shares this call's trials, or None: one trial, one usable device, a
+        process group that already exists (launched under torch.distributed.run: the ranks shard among themselves), or
+        BREACH_HIP_TRIAL_DEVICES / cfg.impl.trial_devices naming a single device."""
+        import torch.distributed as dist
+
+        if getattr(self, "_is_trial_worker", False) or num_trials < 2:
+            return None
+        pool = getattr(self, "_pool", None)
+        if pool is not None and not pool.closed:
+            return pool
+        if dist.is_available() and dist.is_initialized():
+            return None
+        devices = workers.requested_devices(self.cfg, self.setup["device"])[:num_trials]
+        if len(devices) < 2:
+            return None
+        template = copy.deepcopy(self.model_template).to("cpu")
+        loss_fn = copy.deepcopy(self.loss_fn).to("cpu") if isinstance(self.loss_fn, torch.nn.Module) else self.loss_fn
+        self._pool = workers.TrialWorkerPool(devices, workers.attacker_runner_factory,
+                                             (type(self).__name__, template, loss_fn, self.cfg))
+        return self._pool
+
+    def close(self):
+        """Stop the trial workers (also happens when the attacker is garbage collected)."""
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.close()
+            self._pool = None
+
+    def _adopt_initial_state(self, state):
+        out = []
+        for tensor in state:
+            t = tensor.detach().to(**self.setup).contiguous().requires_grad_(True)
+            t.grad = torch.zeros_like(t)
+            out.append(t)
+        return tuple(out)
 
     # hooks the joint attacker overrides -------------------------------------------------------------------------
     def _draw_initial_state(self, num_points, labels):
@@ -850,6 +910,10 @@ class FusedTrial:
         signed = optim.signed
         sign_mode = _lib.SIGN_HARD if signed == "hard" else _lib.SIGN_SOFT if signed == "soft" else _lib.SIGN_NONE
         self.langevin = float(optim.langevin_noise or 0.0)
+        # impl.langevin_noise=host: draw the noise from torch's default CPU generator and copy it over -- what a CPU run of the
+        # reference draws from the same seed, so parity tests can put identical noise on both sides.  The copy synchronises,
+        # hence no graph replay in this mode; the default draws on the device.
+        self.host_noise = self.langevin > 0 and _cfg_get(cfg.impl, "langevin_noise", "device") == "host"
         self.grad_clip = optim.grad_clip
         self.slots = []  # per optimised tensor: params struct + moment buffers + best copy
         for tensor, boxed in zip(self.candidates, attacker._boxed_flags(self.candidates)):
@@ -879,13 +943,13 @@ class FusedTrial:
         with torch.cuda.device(device):
             _lib.check(lib.bh_state_reset(_lib.ptr(self.state), _lib.current_stream_handle(device)), "bh_state_reset")
         self.iterations = 0
-        self.tickets = {}  # zeroed device words for kernel A's last-arriver epilogue, one per gradient-match plan
+        self.tickets = {}  # zeroed device words for kernel D's layer-total ticket, one per model
         # hipGraph replay of the whole iteration: the loop is launch-bound (~1.2k kernels per ResNet-18 iteration), and
         # nothing in step() needs the host, so after a few eager iterations the body is captured once and replayed.
         self.graph = None
         self.graph_failed = None
         self.capture_after = GRAPH_WARMUP_ITERATIONS
-        self.use_graph = graph_replay_enabled(cfg)
+        self.use_graph = graph_replay_enabled(cfg) and not self.host_noise
 
     def step(self):
         """One attack iteration: a graph replay when captured, the eager body otherwise."""
@@ -929,8 +993,8 @@ class FusedTrial:
             stream = _lib.current_stream_handle(device)
             for tensor in self.candidates:
                 tensor.grad = None
-            scoped = [att.objective] + [reg for reg in self.autograd_regs if hasattr(reg, "ticket_scope")]
-            for owner in scoped:  # this trial's forwards all run on this stream: one re-zeroed ticket word per plan
+            scoped = [reg for reg in self.autograd_regs if hasattr(reg, "ticket_scope")]
+            for owner in scoped:  # this trial's launches all run on this stream: one re-zeroed ticket word per BN plan
                 owner.ticket_scope = self.tickets
             try:
                 total_objective, task_loss = att._autograd_objective(self.candidates, self.labels, self.rec_model,
@@ -958,7 +1022,9 @@ class FusedTrial:
             for idx, (slot, grad) in enumerate(zip(self.slots, grads)):
                 grad = grad.contiguous()
                 reg_grad = self.prior_grad if (self.use_prior and idx == 0) else None
-                noise = torch.randn_like(grad) if self.langevin > 0 else None
+                noise = None
+                if self.langevin > 0:  # optimization_based_attack.py:169
+                    noise = torch.randn(grad.shape, dtype=grad.dtype).to(grad.device) if self.host_noise else torch.randn_like(grad)
                 if self.grad_clip is not None:
                     _lib.check(
                         lib.bh_grad_norm(_lib.ptr(self.state), _lib.ptr(grad), _lib.ptr(reg_grad), _lib.ptr(noise),

@@ -8,11 +8,13 @@
 // iteration, so their base pointers travel in the kernel-argument segment (no device table to refresh, no copy,
 // graph-capture friendly).  The observed gradient and the output gradient live in packed flat buffers.  Work is
 // cut into chunks of BH_GM_CHUNK elements that never straddle a tensor.  The forward launch is a PERSISTENT grid of at
-// most BH_GM_MAX_ROWS 256-thread workgroups (8 per CU = full occupancy on 256 CUs, no tail wave): workgroup w streams
-// chunks w, w+G, w+2G, ... with 16-byte loads (4 per thread per operand in flight), keeps fp32 sums per chunk and fp64
-// sums across chunks, reduces once with wave64 shuffles + LDS and writes ONE row of fp64 partial sums.  The workgroup
-// that finishes last (device-scope ticket) combines the <= 2048 rows in a fixed order and runs the objective epilogue,
-// so forward + finalize is a single launch; a stand-alone finalize kernel does the same for callers that want it.
+// most BH_GM_MAX_ROWS (default cap 512 = two per CU) 256-thread workgroups, all resident at once, no tail wave:
+// workgroup w streams chunks w, w+G, w+2G, ... with 16-byte loads (4 per thread per operand in flight), keeps fp32 sums
+// per chunk and fp64 sums across chunks, reduces once with wave64 shuffles + LDS and writes ONE row of fp64 partial
+// sums.  A one-workgroup finalize kernel combines the <= 512 rows (two per thread) in a fixed order and runs the
+// objective epilogue.  (Measured and rejected, profiles/r2_kernel_bench_fused_vs_twolaunch.json: letting the last
+// workgroup to finish do the combine in the same launch -- the agent-scope release fence + ticket costs ~30 ns per
+// workgroup, serialised: +13 us at 483 workgroups, +44 us at 1447.)
 //
 // Roofline: HBM-bound, 2*N*4 bytes forward, 3*N*4 bytes backward (N = total elements).  No MFMA: <= 2 flop/byte.
 
@@ -109,16 +111,16 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
 }
 
 // Fixed-order combine of `n_rows` partial rows by ONE 256-thread workgroup, then the epilogue: thread t sums rows
-// t, t+256, ... (at most 8 for a single launch group), wave64 shuffles, one LDS slot per wave, thread 0 finishes.  Each
+// t, t+256, ... (two for a single launch group at the default cap), wave64 shuffles, one LDS slot per wave, thread 0 finishes.  Each
 // row also carries the wall-clock stamps of its workgroup; their envelope is the span of the forward launch.
-__device__ void gm_combine_rows(int kind, const double* partials, int n_rows, float scale, float tag_scale,
+__device__ void gm_combine_rows(int kind, const double* __restrict__ partials, int n_rows, float scale, float tag_scale,
                                 float fudge, float* __restrict__ stats, double* __restrict__ span_accum, double* lds,
                                 int* span_lds) {
   double v[3] = {0.0, 0.0, 0.0};
   const unsigned int base_tick =
       (unsigned int)((unsigned long long)__double_as_longlong(partials[BH_GM_PARTIAL_STRIDE - 1]) >> 32);
   int lo = 0x7fffffff, hi = -0x7fffffff;
-  const double4* rows = reinterpret_cast<const double4*>(partials);  // written by other workgroups: no __restrict__
+  const double4* __restrict__ rows = reinterpret_cast<const double4*>(partials);
   for (int row = threadIdx.x; row < n_rows; row += kBlock) {
     const double4 p = rows[row];
     v[0] += p.x;
@@ -162,24 +164,12 @@ __device__ void gm_combine_rows(int kind, const double* partials, int n_rows, fl
   gm_epilogue(kind, v, scale, tag_scale, fudge, span_ticks, stats);
 }
 
-// What the last workgroup of a forward launch needs to finish the objective (all by value in the kernel arguments).
-struct GmFused {
-  unsigned int* counter;       // device ticket, zero before the first launch group; reset by the finisher.  NULL = off
-  unsigned int ticket_target;  // workgroups of ALL launch groups of this forward call
-  int total_rows;              // rows of all launch groups
-  int kind;
-  float scale, fudge;
-  float* stats;
-  double* span_accum;
-};
-
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
                                                         const bh_gm_chunk* __restrict__ chunks, int chunk_begin,
                                                         int chunk_end, const float* __restrict__ weights, float tag_scale,
-                                                        double* partials, int row_base, GmFused fused) {
+                                                        double* __restrict__ partials, int row_base) {
   __shared__ double lds[bh::kWavesPerBlock * 3];
-  __shared__ int span_lds[bh::kWavesPerBlock * 2];
   const int tid = threadIdx.x;
   // constant-rate wall clock at block entry (thread 0 only): lets the combine step report the launch's true span
   const unsigned int tick0 = tid == 0 ? (unsigned int)wall_clock64() : 0u;
@@ -220,7 +210,6 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
     acc[2] += s2;
   }
   bh::block_sum<3>(acc, lds);
-  __shared__ int finisher;
   if (tid == 0) {
     double* row = partials + (int64_t)(row_base + blockIdx.x) * BH_GM_PARTIAL_STRIDE;
     row[0] = acc[0];
@@ -228,23 +217,10 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
     row[2] = acc[2];
     const unsigned long long packed = ((unsigned long long)tick0 << 32) | (unsigned int)wall_clock64();
     row[3] = __longlong_as_double((long long)packed);
-    int last = 0;
-    if (fused.counter != nullptr) {
-      __threadfence();  // release the row to the other XCDs' L2s before taking a ticket
-      last = atomicAdd(fused.counter, 1u) == fused.ticket_target - 1u;
-    }
-    finisher = last;
   }
-  if (fused.counter == nullptr) return;
-  __syncthreads();
-  if (!finisher) return;
-  __threadfence();  // acquire: every other workgroup's row is visible now
-  gm_combine_rows(fused.kind, partials, fused.total_rows, fused.scale, tag_scale, fused.fudge, fused.stats,
-                  fused.span_accum, lds, span_lds);
-  if (tid == 0) *fused.counter = 0u;  // ready for the next forward call on this stream
 }
 
-// Stand-alone combine + epilogue (one workgroup): same arithmetic as the fused finisher.
+// Combine + epilogue (one workgroup).
 __global__ __launch_bounds__(kBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials, int n_rows,
                                                              float scale, float tag_scale, float fudge,
                                                              float* __restrict__ stats, double* __restrict__ span_accum) {
@@ -357,13 +333,13 @@ struct LaunchEvents {
 template <int KIND>
 void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_begin,
                 int chunk_end, int grid, const float* weights, float tag_scale, double* partials, int row_base,
-                const GmFused& fused, hipStream_t st, LaunchEvents ev) {
+                hipStream_t st, LaunchEvents ev) {
   if (ev.start || ev.stop)
     hipExtLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
-                          data_flat, chunks, chunk_begin, chunk_end, weights, tag_scale, partials, row_base, fused);
+                          data_flat, chunks, chunk_begin, chunk_end, weights, tag_scale, partials, row_base);
   else
     hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
-                       chunk_begin, chunk_end, weights, tag_scale, partials, row_base, fused);
+                       chunk_begin, chunk_end, weights, tag_scale, partials, row_base);
 }
 
 template <int KIND>
@@ -387,8 +363,9 @@ LaunchEvents group_events(void* ev_start, void* ev_stop, bool first, bool last) 
 }
 
 // Persistent-grid size for a launch group of n chunks: every workgroup gets the same number of chunks (+-1) and the
-// whole grid is resident at once (<= rows_cap workgroups; 2048 = 8 per CU on 256 CUs).
-int g_rows_cap = BH_GM_MAX_ROWS;
+// whole grid is resident at once.  Cap 512 (two workgroups per CU, 8 x 16 B loads in flight per thread) measured fastest
+// or equal at every BASELINE size: BERT-base 109.7 us vs 117.6 us at 2048, ResNet-50 32.0 vs 33.0, ResNet-18 17.5 = 17.5.
+int g_rows_cap = BH_GM_DEFAULT_ROWS;
 
 int group_rows(int n_chunks_in_group) {
   if (n_chunks_in_group <= 0) return 0;
@@ -472,31 +449,18 @@ int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin) {
 
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, const bh_gm_fused* fused, void* stream,
-              void* ev_start, void* ev_stop) {
+              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
+              void* ev_stop) {
   if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
       n_chunks <= 0 || group_chunk_begin == nullptr || partials_dev == nullptr)
     return BH_EINVAL;
   if ((reinterpret_cast<uintptr_t>(partials_dev) & 31u) != 0) return BH_EINVAL;  // rows are read as 32-byte vectors
   if (kind == BH_GM_TAG && weights_dev == nullptr) return BH_EINVAL;
-  if (fused != nullptr && (fused->counter_dev == nullptr || fused->stats_dev == nullptr)) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   const int groups = bh_gm_num_groups(n_tensors);
   for (int g = 0; g < groups; ++g) {  // validate every pointer before anything is enqueued
     GmPtrs probe;
     if (!fill_ptrs(probe, rec_ptrs, n_tensors, g)) return BH_EINVAL;
-  }
-  const int total_rows = bh_gm_fwd_rows(n_tensors, group_chunk_begin);
-  GmFused dev_fused{};
-  if (fused != nullptr) {
-    dev_fused.counter = static_cast<unsigned int*>(fused->counter_dev);
-    dev_fused.ticket_target = (unsigned int)total_rows;
-    dev_fused.total_rows = total_rows;
-    dev_fused.kind = kind;
-    dev_fused.scale = fused->scale;
-    dev_fused.fudge = fused->fudge;
-    dev_fused.stats = fused->stats_dev;
-    dev_fused.span_accum = fused->span_accum_dev;
   }
   int row_base = 0;
   for (int g = 0; g < groups; ++g) {
@@ -508,7 +472,7 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
     const int tb = g * BH_GM_MAX_PTRS;
     const LaunchEvents ev = group_events(ev_start, ev_stop, begin == 0, end == n_chunks);
 #define BH_FWD(K) \
-  launch_fwd<K>(ptrs, tb, data_flat, chunks_dev, begin, end, grid, weights_dev, tag_scale, partials_dev, row_base, dev_fused, st, ev)
+  launch_fwd<K>(ptrs, tb, data_flat, chunks_dev, begin, end, grid, weights_dev, tag_scale, partials_dev, row_base, st, ev)
     switch (kind) {
       case BH_GM_COSINE:
       case BH_GM_COSINE_FAST:

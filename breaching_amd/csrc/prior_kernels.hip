@@ -281,13 +281,15 @@ __global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_b
 // the running statistics, the layer's weighted statistic and the backward coefficients
 //   d (w * r) / d x[b,c,hw] = A_c + B_c * x[b,c,hw].
 // The workgroup that finishes last adds the layers up in index order (fixed order => reproducible) into total[0].
-__global__ __launch_bounds__(kBlock) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
+constexpr int kBnFinBlock = 1024;  // C up to 2048 channels per layer: two per thread
+
+__global__ __launch_bounds__(kBnFinBlock) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
                                                              const double* __restrict__ sums,
                                                              const float* __restrict__ running_mean,
                                                              const float* __restrict__ running_var,
                                                              float* __restrict__ coef, double* layer_values,
                                                              float* __restrict__ total, unsigned int* counter) {
-  __shared__ double lds[bh::kWavesPerBlock * 2];
+  __shared__ double lds[(kBnFinBlock / bh::kWave) * 2];
   __shared__ double norms[2];
   __shared__ int finisher;
   const bh_bn_layer L = layers[blockIdx.x];
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(int n_layers, const
     var = var < 0.0 ? 0.0 : var;
   };
   double v[2] = {0.0, 0.0};  // sum (rv - var)^2, sum (rm - mean)^2
-  for (int c = threadIdx.x; c < L.C; c += kBlock) {
+  for (int c = threadIdx.x; c < L.C; c += kBnFinBlock) {
     double mean, var;
     channel_stats(c, mean, var);
     const double dvv = (double)running_var[L.chan_off + c] - var, dm = (double)running_mean[L.chan_off + c] - mean;
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(kBlock) void bn_finalize_kernel(int n_layers, const
   }
   __syncthreads();
   const double nv = norms[0], nm = norms[1], w = (double)L.weight;
-  for (int c = threadIdx.x; c < L.C; c += kBlock) {
+  for (int c = threadIdx.x; c < L.C; c += kBnFinBlock) {
     double mean, var;
     channel_stats(c, mean, var);
     const double pv = nv > 0.0 ? -((double)running_var[L.chan_off + c] - var) / nv : 0.0;   // d r / d var_c
@@ -563,7 +565,7 @@ int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double
       total_dev == nullptr || counter_dev == nullptr)
     return BH_EINVAL;
   if ((reinterpret_cast<uintptr_t>(coef_dev) & 7u) != 0) return BH_EINVAL;  // read back as float2
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(n_layers), dim3(kBlock), 0, bh::as_stream(stream), n_layers, layers_dev,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(n_layers), dim3(kBnFinBlock), 0, bh::as_stream(stream), n_layers, layers_dev,
                      sums_dev, running_mean, running_var, coef_dev, layer_values_dev, total_dev,
                      static_cast<unsigned int*>(counter_dev));
   return bh::launch_status();

@@ -12,17 +12,12 @@ per-parameter gradient list and its derivative run here.
 """
 
 import ctypes
-import os
 from ctypes import c_int32, c_int64, c_void_p
 
 import torch
 from torch.autograd.function import once_differentiable
 
 from . import _lib
-
-
-# forward + finalize as one launch (last-arriver epilogue); BREACH_HIP_FUSED_FINALIZE=0 selects the two-launch form
-FUSED_FINALIZE = os.environ.get("BREACH_HIP_FUSED_FINALIZE", "1") != "0"
 
 
 def _require_cuda(t, what):
@@ -108,7 +103,7 @@ class GradientMatchPlan:
         return (total / count) / (khz / 1e3) if count > 0 and khz > 0 else None, int(count)
 
     def enable_timing(self):
-        self.timers = dict(fwd=[], bwd=[])
+        self.timers = dict(fwd=[], fin=[], bwd=[])
 
     def _timed(self, key):
         """A fresh (start, stop) pair of hipEvent handles, recorded by the C side right around the launch."""
@@ -179,36 +174,30 @@ class GradientMatchPlan:
         return True
 
     # -- launches --------------------------------------------------------------------------------------------------
-    def forward(self, kind, rec, scale, tag_scale=0.0, fudge=1e-7, weights=None, ticket=None, fused=True):
-        """Enqueue the forward reduction; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS].
-
-        One launch: the last workgroup combines the rows and writes the record (``fused``).  ``ticket`` is the zeroed
-        int32 device word that launch uses to find its last workgroup; the finisher re-zeroes it, so a caller that issues
-        its forwards on one stream passes the same word every time (``FusedTrial`` owns one per plan).  Without a ticket a
-        fresh zero word is made for the call.  ``fused=False`` runs the stand-alone finalize kernel instead."""
+    def forward(self, kind, rec, scale, tag_scale=0.0, fudge=1e-7, weights=None):
+        """Enqueue forward reduction + finalize; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS]."""
         lib = _lib.load()
         stats = torch.empty(_lib.BH_GM_STAT_WORDS, dtype=torch.float32, device=self.device)
-        # per-call workspace (64 KB): trials that run concurrently on different streams share this plan
+        # per-call workspace (16 KB): trials that run concurrently on different streams share this plan
         partials = torch.empty(self.n_rows * _lib.BH_GM_PARTIAL_STRIDE, dtype=torch.float64, device=self.device)
         stream = _lib.current_stream_handle(self.device)
         ptrs = self._pointer_array(rec)
         ev0, ev1 = self._timed("fwd")
-        epilogue = None
-        if fused:
-            if ticket is None:
-                ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
-            epilogue = _lib.GmFused(_lib.ptr(ticket), _lib.ptr(stats), _lib.ptr(self.span_accum), float(scale), float(fudge))
         _lib.check(
             lib.bh_gm_fwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), epilogue, stream, ev0, ev1),
+                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), stream, ev0, ev1),
             "bh_gm_fwd",
         )
-        if not fused:
-            _lib.check(
-                lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_rows, float(scale), float(tag_scale), float(fudge),
-                                   _lib.ptr(stats), _lib.ptr(self.span_accum), stream),
-                "bh_gm_finalize",
-            )
+        ev0, ev1 = self._timed("fin")
+        if ev0 is not None:
+            _lib.check(lib.bh_event_record(ev0, stream), "bh_event_record")
+        _lib.check(
+            lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_rows, float(scale), float(tag_scale), float(fudge),
+                               _lib.ptr(stats), _lib.ptr(self.span_accum), stream),
+            "bh_gm_finalize",
+        )
+        if ev1 is not None:
+            _lib.check(lib.bh_event_record(ev1, stream), "bh_event_record")
         return stats
 
     def backward(self, kind, rec, stats, gout, weights=None):
@@ -233,10 +222,10 @@ class _GradMatchFunction(torch.autograd.Function):
     """objective(rec_0, ..., rec_{T-1}) as one differentiable node; backward hands autograd T views of one buffer."""
 
     @staticmethod
-    def forward(ctx, plan, kind, scale, tag_scale, fudge, weights, ticket, *rec):
+    def forward(ctx, plan, kind, scale, tag_scale, fudge, weights, *rec):
         rec = plan._prepare(rec)
         with torch.cuda.device(plan.device):
-            stats = plan.forward(kind, rec, scale, tag_scale, fudge, weights, ticket=ticket, fused=FUSED_FINALIZE)
+            stats = plan.forward(kind, rec, scale, tag_scale, fudge, weights)
         ctx.plan, ctx.kind, ctx.weights, ctx.stats = plan, kind, weights, stats
         ctx.n_inputs = len(rec)
         ctx.save_for_backward(*rec)
@@ -251,7 +240,7 @@ class _GradMatchFunction(torch.autograd.Function):
         with torch.cuda.device(plan.device):
             grad_flat = plan.backward(ctx.kind, rec, ctx.stats, gout, ctx.weights)
         grads = plan.split(grad_flat)
-        return (None, None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, *grads)
 
 
 class HipGradientLoss(torch.nn.Module):
@@ -264,7 +253,6 @@ class HipGradientLoss(torch.nn.Module):
         self.scale = scale
         self.task_regularization = task_regularization
         self._plans = []
-        self.ticket_scope = None
 
     @property
     def _plan(self):
@@ -325,20 +313,7 @@ class HipGradientLoss(torch.nn.Module):
         tag_scale, fudge = self._extra()
         kind = _lib.GM_KINDS[self.kind_name]
         return _GradMatchFunction.apply(plan, kind, float(self.scale), tag_scale, fudge,
-                                        self._weights(plan, len(gradient_rec)), self._ticket(plan),
-                                        *gradient_rec[: plan.n_tensors])
-
-    def _ticket(self, plan):
-        """The zeroed device word the fused forward uses to find its last workgroup.  Inside a ``ticket_scope`` (a dict owned
-        by one trial, whose forwards are all on one stream) one word per plan is reused forever -- the finisher re-zeroes
-        it; outside (scoring, L-BFGS closures) every call gets a fresh word."""
-        scope = self.ticket_scope
-        if scope is None:
-            return None
-        ticket = scope.get(id(plan))
-        if ticket is None:
-            ticket = scope[id(plan)] = torch.zeros(1, dtype=torch.int32, device=plan.device)
-        return ticket
+                                        self._weights(plan, len(gradient_rec)), *gradient_rec[: plan.n_tensors])
 
     # objectives.py:40-46
     def _single_step_gradient(self, model, candidate, labels):

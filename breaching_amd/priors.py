@@ -255,7 +255,7 @@ class HipDeepInversion(torch.nn.Module):
         self.first_bn_multiplier = first_bn_multiplier
         self.losses = []
         self._plans = {}
-        self.ticket_scope = None  # dict owned by a trial: one re-zeroed ticket word per model (see gm.HipGradientLoss)
+        self.ticket_scope = None  # dict owned by a trial (FusedTrial.tickets): one re-zeroed ticket word per model
 
     def initialize(self, models, *args, **kwargs):
         # The reference re-registers hooks on every trial and never removes the old ones (regularizers.py:214-220);

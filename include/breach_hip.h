@@ -43,8 +43,10 @@ extern "C" {
 #define BH_GM_MAX_PTRS 448
 /* Doubles per row of the partial-sum workspace (one row per persistent workgroup of the forward launch). */
 #define BH_GM_PARTIAL_STRIDE 4
-/* Workgroups (= rows) of one forward launch group at most: 8 resident 256-thread workgroups per CU on 256 CUs. */
+/* Workgroups (= rows) of one forward launch group: upper bound of the tuning knob, and its default (two resident
+ * 256-thread workgroups per CU on 256 CUs -- measured fastest, see gm_kernels.hip). */
 #define BH_GM_MAX_ROWS 2048
+#define BH_GM_DEFAULT_ROWS 512
 
 /* One entry of the chunk table (24 bytes, device resident, built once per attack by bh_gm_build_table). */
 typedef struct bh_gm_chunk {
@@ -88,34 +90,20 @@ int bh_gm_table_size(int32_t n_tensors, const int64_t* numel, int64_t* n_chunks,
 int bh_gm_build_table(int32_t n_tensors, const int64_t* numel, bh_gm_chunk* chunks, int64_t n_chunks,
                       int64_t* tensor_flat_off);
 
-/* Optional fused finalize of bh_gm_fwd: the workgroup that finishes last combines all rows and writes the statistics
- * record, so forward + finalize is ONE launch.  `counter_dev` is a 4-byte device word that must be zero before the
- * call; the finisher resets it to zero, so the same word serves every later call on the same stream (calls that may
- * overlap -- different streams -- need their own word). */
-typedef struct bh_gm_fused {
-  void* counter_dev;      /* uint32 ticket, zero-initialised once by the caller */
-  float* stats_dev;       /* BH_GM_STAT_WORDS floats, as written by bh_gm_finalize */
-  double* span_accum_dev; /* optional, see bh_gm_finalize */
-  float scale;            /* objective scale (`* self.scale`, objectives.py:86, :126, :155, :178) */
-  float fudge;            /* AngularSimilarity clamp margin (objectives.py:208) */
-} bh_gm_fused;
-
 /* Forward reduction.  `rec_ptrs` is a HOST array of `n_tensors` DEVICE pointers (the tensors returned by
  * autograd this iteration, each contiguous fp32 and 16-byte aligned); `data_flat` is the packed observed gradient;
  * `chunks_dev` the device chunk table; `weights_dev` per-tensor fp32 weights (BH_GM_TAG only, else NULL).
  * The launch is a persistent grid: bh_gm_fwd_rows() workgroups, each streaming every G-th chunk and writing ONE row
  * of BH_GM_PARTIAL_STRIDE doubles into `partials_dev` (32-byte aligned, bh_gm_fwd_rows rows; overwritten, never
  * accumulated).  `group_chunk_begin` (HOST, bh_gm_num_groups+1 entries, from bh_gm_group_bounds) delimits the chunks
- * of every launch group.  With `fused` non-NULL the statistics record is complete when the call's work is done; with
- * NULL the caller follows up with bh_gm_finalize(kind, partials_dev, bh_gm_fwd_rows(...), ...).
- * reference: objectives.py:89-95, 133-141, 158-166, 183-196, 233-244, 259-273 (the list reductions) and their
- * epilogues :95, :141, :166, :195, :211-214, :243, :271. */
+ * of every launch group.  The caller follows up with bh_gm_finalize(kind, partials_dev, bh_gm_fwd_rows(...), ...).
+ * reference: objectives.py:89-95, 133-141, 158-166, 183-196, 233-244, 259-273 (the list reductions). */
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, const bh_gm_fused* fused, void* stream,
-              void* ev_start, void* ev_stop);
+              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
+              void* ev_stop);
 /* Rows (= workgroups over all launch groups) bh_gm_fwd writes for this list: chunks are dealt out evenly to at most
- * `rows cap` workgroups per launch group (default BH_GM_MAX_ROWS).  Negative on invalid arguments. */
+ * `rows cap` workgroups per launch group (default BH_GM_DEFAULT_ROWS).  Negative on invalid arguments. */
 int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin);
 /* Tuning knob (process global, host side): cap of workgroups per forward launch group, 1..BH_GM_MAX_ROWS. */
 int32_t bh_gm_set_rows_cap(int32_t cap);
@@ -130,8 +118,8 @@ int32_t bh_gm_num_groups(int32_t n_tensors);
 int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_t n_chunks,
                        int32_t* group_chunk_begin);
 
-/* Stand-alone fixed-order combine of the partial rows and objective epilogue (what the fused finisher of bh_gm_fwd
- * does in-kernel): writes BH_GM_STAT_WORDS floats to `stats_dev`.
+/* Fixed-order combine of the partial rows and objective epilogue (one workgroup): writes BH_GM_STAT_WORDS floats to
+ * `stats_dev`.
  * `fudge` is AngularSimilarity's clamp margin (objectives.py:208, 1e-7); ignored otherwise.
  * reference: objectives.py:95 (0.5*objective), :141, :166, :195, :211-214, :243, :271 and the `* self.scale`
  * at :86, :126, :155, :178. */

@@ -517,6 +517,65 @@ def golden_seethrough():
     np.savez_compressed(os.path.join(GOLDEN, "attack_seethrough.npz"), **out)
 
 
+def golden_seethrough_b8():
+    """BASELINE configs[2] at its real batch size: ResNet-50, 8 images, see-through-gradients (euclidean 1e-4 + TV + L2 norm +
+    DeepInversion 0.1), Langevin noise 0.01 ON, labels recovered with `yin`, user-supplied BN buffers; 12 iterations with a
+    3-iteration warm-up so the cosine schedule moves.  The noise is what torch's seeded default CPU generator produces
+    (the reference on CPU draws it there, optimization_based_attack.py:167-170); the HIP test re-creates the same stream
+    (`impl.langevin_noise=host`), so the two sides see identical noise tensors."""
+    from breaching_amd.cases import build_case, initial_candidate
+
+    torch.set_num_threads(8)
+    case = build_case("resnet50", "ImageNet", 8, provide_buffers=True, provide_labels=False)
+    x0 = initial_candidate(case.data_cfg, 8)
+    cfg = _cfg("seethroughgradients", ["optim.max_iterations=12", "optim.warmup=3", "optim.callback=4"])
+    assert cfg.optim.langevin_noise == 0.01 and cfg.label_strategy == "yin"
+    rec, stats = _run_reference_attack(cfg, case, x0, seed=11)
+    out = _attack_record(cfg, case, x0, rec, stats, crop=32)
+    out.update(seed=np.int64(11), true_labels=case.true_user_data["labels"].numpy())
+    twins, twin_psnr, twin_opt = [], [], []
+    from breaching_amd.cases import psnr
+
+    gen = torch.Generator().manual_seed(123)
+    rec_t, stats_t = _run_reference_attack(cfg, case, _ulp_perturb(x0, 16, gen), seed=11)  # same noise, start 16 ulp away
+    out.update(twin_history=np.asarray([stats_t["Trial_0_Val"]], dtype=np.float64),
+               twin_psnr=np.asarray([psnr(rec_t["data"], case.true_user_data["data"], case.data_cfg)]),
+               twin_opt_value=np.asarray([stats_t["opt_value"]]))
+    np.savez_compressed(os.path.join(GOLDEN, "attack_seethrough_b8.npz"), **out)
+
+
+def golden_tag_bert_base():
+    """BASELINE configs[4] at its real size: BERT-base masked-LM (BertConfig() defaults, 109.5 M parameters), sequence
+    length 32, TAG joint attack (tag-euclidean over 201 of the 202 tensors: the word-embedding gradient is cut off, the
+    tied decoder weight makes the reconstructed list one longer than the observed one), AdamW, clipping, warm-up + linear
+    decay; 12 iterations.  Run by the reference's OptimizationJointAttacker on CPU."""
+    breaching = import_reference(preload_transformers=True)
+    from breaching_amd.cases import build_text_case, parameter_checksum
+
+    torch.set_num_threads(8)
+    out = {}
+    over = ["optim.max_iterations=12", "optim.callback=4", "optim.warmup=3"]
+    for tag, seed in (("", 3), ("twin_", 4)):
+        case = build_text_case(full_size=True, seq_len=32)
+        cfg = _cfg("tag", over)
+        attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+        torch.manual_seed(seed)
+        rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {})
+        out[f"{tag}history"] = np.asarray(stats["Trial_0_Val"], dtype=np.float64)
+        out[f"{tag}opt_value"] = np.float64(stats["opt_value"])
+        out[f"{tag}tokens"] = rec["data"].numpy()
+        out[f"{tag}labels"] = rec["labels"].numpy()
+        out[f"{tag}raw_embeddings"] = rec["raw_embeddings"].numpy()
+        out[f"{tag}seed"] = np.int64(seed)
+        if tag == "":
+            out["n_observed"] = np.int64(len(case.shared_data[0]["gradients"]))  # after the embedding gradient was popped
+            out["n_parameters"] = np.int64(sum(1 for _ in case.model.parameters()))
+            out["model_checksum"] = np.float64(parameter_checksum(case.model))
+            out["true_tokens"] = case.true_user_data["data"].numpy()
+            out["grad_checksum"] = np.float64(sum(float(g.double().sum()) for g in case.shared_data[0]["gradients"]))
+    np.savez_compressed(os.path.join(GOLDEN, "attack_tag_bert_base.npz"), **out)
+
+
 def golden_tag():
     """BASELINE config 5 family: TAG joint data+label attack (tag-euclidean, AdamW, clipping, warm-up + linear decay) on a
     tiny random-init BERT masked-LM, run by the reference's OptimizationJointAttacker."""
@@ -545,8 +604,8 @@ def golden_tag():
 STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_schedules, convnet=golden_convnet,
              resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
              variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg,
-             resnet18_long=golden_resnet18_long)
-SLOW_STEPS = ("resnet18_long",)  # hours of CPU: only run when asked for by name
+             resnet18_long=golden_resnet18_long, seethrough_b8=golden_seethrough_b8, tag_bert_base=golden_tag_bert_base)
+SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base")  # hours of CPU: only run when asked for by name
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()

@@ -42,32 +42,32 @@ def gm_case(name, shapes):
         kind = _lib.GM_KINDS[kind_name]
         weights = torch.linspace(1, 0.1, len(shapes), device=dev) if kind_name == "tag-euclidean" else None
         plan.enable_timing()
-        ticket = torch.zeros(1, dtype=torch.int32, device=dev)
         for _ in range(30):
-            stats = plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights, ticket=ticket)
+            stats = plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights)
             plan.backward(kind, rec, stats, None, weights)
         t = plan.drain_timers()
         fwd = sorted(t["fwd"])[5:]
+        fin = sorted(t["fin"])[5:]
         bwd = sorted(t["bwd"])[5:]
-        f, b = sum(fwd) / len(fwd), sum(bwd) / len(bwd)
-        res[kind_name] = dict(fwd_us=round(f, 2), fwd_GBs=round(2 * n * 4 / f / 1e3, 1), bwd_us=round(b, 2), bwd_GBs=round(3 * n * 4 / b / 1e3, 1))
+        f, e, b = sum(fwd) / len(fwd), sum(fin) / len(fin), sum(bwd) / len(bwd)
+        res[kind_name] = dict(fwd_us=round(f, 2), fwd_GBs=round(2 * n * 4 / f / 1e3, 1), finalize_us=round(e, 2),
+                              stage_GBs=round(2 * n * 4 / (f + e) / 1e3, 1), bwd_us=round(b, 2), bwd_GBs=round(3 * n * 4 / b / 1e3, 1))
     res.update(tensors=len(shapes), elements=n, chunks=plan.n_chunks, rows=plan.n_rows)
-    # forward stage (reduction + objective epilogue) under the knobs: rows cap x fused / two-launch finalize.
-    # events: dispatch begin -> end of the forward launch(es) alone; burst: back-to-back stage time incl. the epilogue launch
+    # forward stage (reduction + finalize) against the persistent-grid size.  events: dispatch begin -> end of the forward
+    # launch alone / event pair around the finalize launch; burst: back-to-back stage time incl. both launch boundaries
     sweep = {}
-    for cap in (512, 1024, 1536, 2048):
+    for cap in (128, 256, 384, 512, 768, 1024, 2048):
         lib.bh_gm_set_rows_cap(cap)
         p2 = GradientMatchPlan(data)
-        for fused in (True, False):
-            ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-            p2.enable_timing()
-            for _ in range(30):
-                p2.forward(0, rec, 1.0, 0.0, 1e-7, None, ticket=ticket, fused=fused)
-            ev = sorted(p2.drain_timers()["fwd"])[5:]
-            us = burst(lambda: p2.forward(0, rec, 1.0, 0.0, 1e-7, None, ticket=ticket, fused=fused), reps=40)
-            sweep[f"cap{cap}_{'fused' if fused else 'twolaunch'}"] = dict(rows=p2.n_rows, fwd_event_us=round(sum(ev) / len(ev), 2),
-                                                                         stage_burst_us=round(us, 2))
-    lib.bh_gm_set_rows_cap(2048)
+        p2.enable_timing()
+        for _ in range(30):
+            p2.forward(0, rec, 1.0, 0.0, 1e-7, None)
+        t = p2.drain_timers()
+        ev, fin = sorted(t["fwd"])[5:], sorted(t["fin"])[5:]
+        us = burst(lambda: p2.forward(0, rec, 1.0, 0.0, 1e-7, None), reps=40)
+        sweep[f"cap{cap}"] = dict(rows=p2.n_rows, fwd_event_us=round(sum(ev) / len(ev), 2), finalize_us=round(sum(fin) / len(fin), 2),
+                                  stage_burst_us=round(us, 2))
+    lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
     res["forward_stage_sweep_cosine"] = sweep
     out[f"kernelA_{name}"] = res
 

@@ -85,7 +85,7 @@ def test_chunk_table_host_helpers(hip_lib):
     assert list(bounds) == [0, _lib.BH_GM_MAX_PTRS, len(many)]
     # invalid arguments are reported, not crashed on
     assert hip_lib.bh_gm_table_size(-1, arr, byref(n_chunks), byref(flat)) == -1
-    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, None, None, None, None) == -1
+    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, None, None, None) == -1
     assert hip_lib.bh_candidate_step(None, None, None, None, None, None, None, None, None, None, None) == -1
 
 
@@ -119,7 +119,7 @@ def test_header_is_valid_c99(tmp_path):
     assert proc.returncode == 0, proc.stderr
 
 
-@pytest.mark.parametrize("c_name,mirror", [("bh_step_params", "StepParams"), ("bh_gm_fused", "GmFused"), ("bh_gm_chunk", "GmChunk"),
+@pytest.mark.parametrize("c_name,mirror", [("bh_step_params", "StepParams"), ("bh_gm_chunk", "GmChunk"),
                                            ("bh_bn_layer", "BnLayer"), ("bh_bn_item", "BnItem")])
 def test_struct_layouts_match_ctypes(tmp_path, c_name, mirror):
     """sizeof / offsetof of every ABI struct as the C compiler sees them == its ctypes mirror in _lib."""

@@ -346,9 +346,9 @@ def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_li
     assert int(ticket.item()) == 0
 
 
-def test_gm_forward_fused_and_two_launch_finalize_agree(hip_lib):
-    """Forward + epilogue as one launch (last workgroup finishes) == forward launch + stand-alone finalize, bit for bit;
-    the persistent-grid size (rows cap) only changes the fp64 summation order."""
+def test_gm_forward_rows_cap_only_changes_summation_order(hip_lib):
+    """The persistent-grid size (rows cap) deals the chunks out differently; results agree to fp64 summation order, and a
+    list longer than one launch group (> 448 tensors) spreads its rows over the groups."""
     from breaching_amd import _lib
     from breaching_amd.gm import GradientMatchPlan
 
@@ -358,23 +358,21 @@ def test_gm_forward_fused_and_two_launch_finalize_agree(hip_lib):
     rec = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
     results = {}
     try:
-        for cap in (2048, 64, 3):
+        for cap in (2048, 512, 64, 3):
             assert hip_lib.bh_gm_set_rows_cap(cap) == 0
             plan = GradientMatchPlan(data)
             assert plan.n_rows <= 2 * cap
-            ticket = torch.zeros(1, dtype=torch.int32, device=_dev())
             for kind in (0, 4, 6):
                 w = torch.linspace(1.0, 0.1, len(shapes), device=_dev()) if kind == 6 else None
-                fused = [plan.forward(kind, rec, 1.5, 0.1, 1e-7, w, ticket=ticket, fused=True).cpu() for _ in range(2)]
-                plain = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w, fused=False).cpu()
-                assert torch.equal(fused[0][:6], plain[:6]) and torch.equal(fused[1][:6], plain[:6])
-                results[(cap, kind)] = plain[:6].double().numpy()
-            assert int(ticket.item()) == 0
+                first = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w).cpu()
+                again = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w).cpu()
+                assert torch.equal(first[:6], again[:6])  # fixed combine order: bitwise reproducible for a fixed geometry
+                results[(cap, kind)] = first[:6].double().numpy()
     finally:
-        hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_MAX_ROWS)
+        hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
     assert hip_lib.bh_gm_set_rows_cap(0) == -1 and hip_lib.bh_gm_set_rows_cap(4096) == -1
     for kind in (0, 4, 6):
-        for cap in (64, 3):
+        for cap in (512, 64, 3):
             np.testing.assert_allclose(results[(cap, kind)], results[(2048, kind)], rtol=2e-6)
 
 

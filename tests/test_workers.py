@@ -1,0 +1,75 @@
+"""Trial worker pool (breaching_amd/workers.py) on CPU: spawn, gloo rendezvous, job protocol, selection collective, errors.
+
+The attacker itself needs a GPU; here the pool runs a stand-in runner that plays `reconstruct`'s multi-rank part: every rank
+holds the solutions of its trials {t : t mod W == rank}, reports `trials_done`, waits for `go`, then joins
+`TrialShard.select` -- exactly the sequence the attacker drives (attacker.py, reconstruct)."""
+
+import pytest
+import torch
+
+
+def _runner_factory(rank, world, device_index, conn, num_trials):
+    from breaching_amd import trials
+
+    def run(job):
+        if job.get("explode") == rank:
+            raise ValueError("boom")
+        shard = trials.TrialShard.current(num_trials)
+        assert (shard.rank, shard.world) == (rank, world)
+        solutions = {t: torch.full((2, 3), float(t)) for t in shard.local_trials()}
+        scores = {t: job["scores"][t] for t in shard.local_trials()}
+        stats = {f"Trial_{t}_Val": [float(t)] * 3 for t in shard.local_trials()}
+        conn.send(("trials_done",))
+        assert conn.recv()[0] == "go"
+        shard.select(solutions, scores, stats, torch.device("cpu"))
+
+    return run
+
+
+def test_pool_runs_jobs_selects_and_survives_errors():
+    from breaching_amd import trials
+    from breaching_amd.workers import TrialWorkerPool
+
+    num_trials = 5
+    pool = TrialWorkerPool([None, None, None], _runner_factory, (num_trials,))
+    try:
+        assert pool.backend == "gloo" and pool.world == 3
+        for scores in ([3.0, 0.25, 7.0, float("nan"), 0.5], [9.0, 8.0, 7.0, 6.0, 0.125]):
+            pool.submit([dict(scores=scores)] * 2)
+            shard = trials.TrialShard.current(num_trials)
+            assert (shard.rank, shard.world) == (0, 3) and list(shard.local_trials()) == [0, 3]
+            solutions = {t: torch.full((2, 3), float(t)) for t in shard.local_trials()}
+            stats = {f"Trial_{t}_Val": [float(t)] * 3 for t in shard.local_trials()}
+            pool.expect("trials_done")
+            pool.broadcast(("go",))
+            value, solution = shard.select(solutions, {t: scores[t] for t in shard.local_trials()}, stats, torch.device("cpu"))
+            pool.expect("ok")
+            finite = [(s, t) for t, s in enumerate(scores) if s == s]
+            want_value, want_trial = min(finite)
+            assert value == want_value and float(solution[0, 0]) == float(want_trial)
+            assert sorted(stats) == [f"Trial_{t}_Val" for t in range(num_trials)]  # every rank's histories merged
+        # a failing worker reports its traceback; the parent raises instead of waiting in the collective
+        pool.submit([dict(scores=[1.0] * 5, explode=2)] * 2)
+        with pytest.raises(RuntimeError, match="boom"):
+            pool.expect("trials_done")
+    finally:
+        pool.close(force=True)
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def test_requested_devices_parsing(monkeypatch):
+    from breaching_amd import AttrDict
+    from breaching_amd.workers import requested_devices
+
+    cfg = AttrDict(impl=dict(trial_devices=[0, 0]))
+    dev = torch.device("cuda", 0)
+    monkeypatch.delenv("BREACH_HIP_TRIAL_DEVICES", raising=False)
+    assert requested_devices(cfg, dev) == [0, 0]
+    monkeypatch.setenv("BREACH_HIP_TRIAL_DEVICES", "0, 0,0")
+    assert requested_devices(cfg, dev) == [0, 0, 0]
+    monkeypatch.setenv("BREACH_HIP_TRIAL_DEVICES", "1,0")
+    with pytest.raises(ValueError, match="must start with"):
+        requested_devices(cfg, dev)
