@@ -62,6 +62,9 @@ def parse_args():
                    help="timed CPU iterations of the oracle, ~10 s of host work (0 disables)")
     p.add_argument("--model", default="resnet18")
     p.add_argument("--no-kernel-timing", action="store_true")
+    p.add_argument("--no-span-timing", action="store_true",
+                   help="leave the device wall-clock span bookkeeping of kernel A off, as in the product path (it costs the "
+                        "finalize kernel two dependent loads); the in-region span figure is then not reported")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay in the timed region")
     p.add_argument("--roofline-steps", type=int, default=40, help="eager iterations with per-launch HIP events")
     p.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
@@ -84,12 +87,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Bare `python bench.py --gpus N`: launch the N ranks ourselves, exactly the way the driver does, and pass the one
+        # JSON line of rank 0 through.
+        import subprocess
+
+        from breaching_amd.workers import free_port
+
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+        raise SystemExit(subprocess.run(cmd).returncode)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm; gloo only for single-GPU plumbing checks
-    if "BENCH_DEVICE_INDEX" in os.environ:  # several ranks on one GPU (functional check of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+    oversubscribed = world > torch.cuda.device_count()
+    if oversubscribed:
+        # Fewer GPUs than ranks (a 1-GPU box): ranks share devices round-robin and agree over gloo -- RCCL cannot put two
+        # ranks on one device.  A functional check of the N > 1 path only; the line says so ("oversubscribed": true).
+        local_rank = local_rank % torch.cuda.device_count()
+        backend = "gloo"
+    if "BENCH_DEVICE_INDEX" in os.environ:
         local_rank = int(os.environ["BENCH_DEVICE_INDEX"])
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -112,6 +130,9 @@ def main():
     attacker.objective.initialize(attacker.loss_fn, cfg.impl, None)
     for reg in attacker.regularizers:
         reg.initialize(rec_models, case.shared_data, labels)
+    attacker.objective.prepare(rec_models, case.shared_data)  # pack the observed gradient (once, before the loop)
+    for plan in attacker.objective._plans:
+        plan.span_enabled = not args.no_span_timing  # must be set before the iteration is captured into the hipGraph
     x0 = initial_candidate(case.data_cfg, 1, trial=rank).to(device)
     if args.channels_last:
         for m in rec_models:
@@ -292,6 +313,8 @@ def main():
             "graph_capture_error": graph_failed,
             "final_objective": state["total"],
             "select_ms": select_ms,
+            "collective_backend": backend if world > 1 else None,
+            "oversubscribed": bool(oversubscribed),
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -19,6 +19,7 @@ BH_GM_DEFAULT_ROWS = 512
 BH_GM_STAT_WORDS = 8
 BH_PRIOR_MAX_GRID = 1024
 BH_BN_MAX_LAYERS = 448
+BH_MT_MAX_PTRS = 128
 BH_BN_TILE = 4096
 BH_PRIOR_PARTIAL_STRIDE = 2
 BH_STATE_WORDS = 16
@@ -49,6 +50,10 @@ class BnLayer(Structure):
 
 class BnItem(Structure):
     _fields_ = [("layer", c_int32), ("a", c_int32), ("b", c_int32), ("c", c_int32)]
+
+
+class PsnrParams(Structure):
+    _fields_ = [("mean", c_float * 4), ("std", c_float * 4), ("factor", c_float), ("clip", c_int32)]
 
 
 class StepParams(Structure):
@@ -112,6 +117,23 @@ _PROTOTYPES = {
     "bh_bn_bwd": (
         c_int,
         [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "bh_mt_num_groups": (c_int32, [c_int32]),
+    "bh_mt_group_bounds": (c_int, [c_int32, POINTER(GmChunk), c_int64, POINTER(c_int32)]),
+    "bh_mt_axpy": (
+        c_int,
+        [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p), c_float, c_void_p, c_int64, POINTER(c_int32), c_void_p,
+         c_void_p],
+    ),
+    "bh_mt_scale": (c_int, [c_int32, POINTER(c_void_p), c_float, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p]),
+    "bh_mt_patch": (
+        c_int,
+        [c_int32, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p],
+    ),
+    "bh_prior_orthogonality": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
+    "bh_metric_psnr": (
+        c_int,
+        [c_void_p, c_void_p, c_int32, c_int64, c_int64, c_int32, POINTER(PsnrParams), c_void_p, c_void_p, c_void_p],
     ),
     "bh_event_create": (c_int, [POINTER(c_void_p)]),
     "bh_event_destroy": (c_int, [c_void_p]),

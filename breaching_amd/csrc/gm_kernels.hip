@@ -117,8 +117,9 @@ __device__ void gm_combine_rows(int kind, const double* __restrict__ partials, i
                                 float fudge, float* __restrict__ stats, double* __restrict__ span_accum, double* lds,
                                 int* span_lds) {
   double v[3] = {0.0, 0.0, 0.0};
+  const bool want_span = span_accum != nullptr;  // bench-only bookkeeping: off the product path (two dependent loads less)
   const unsigned int base_tick =
-      (unsigned int)((unsigned long long)__double_as_longlong(partials[BH_GM_PARTIAL_STRIDE - 1]) >> 32);
+      want_span ? (unsigned int)((unsigned long long)__double_as_longlong(partials[BH_GM_PARTIAL_STRIDE - 1]) >> 32) : 0u;
   int lo = 0x7fffffff, hi = -0x7fffffff;
   const double4* __restrict__ rows = reinterpret_cast<const double4*>(partials);
   for (int row = threadIdx.x; row < n_rows; row += kBlock) {
@@ -126,19 +127,23 @@ __device__ void gm_combine_rows(int kind, const double* __restrict__ partials, i
     v[0] += p.x;
     v[1] += p.y;
     v[2] += p.z;
-    const unsigned long long packed = (unsigned long long)__double_as_longlong(p.w);
-    const int t0 = (int)((unsigned int)(packed >> 32) - base_tick), t1 = (int)((unsigned int)packed - base_tick);
-    lo = t0 < lo ? t0 : lo;  // wrap safe: 32-bit deltas relative to row 0
-    hi = t1 > hi ? t1 : hi;
+    if (want_span) {
+      const unsigned long long packed = (unsigned long long)__double_as_longlong(p.w);
+      const int t0 = (int)((unsigned int)(packed >> 32) - base_tick), t1 = (int)((unsigned int)packed - base_tick);
+      lo = t0 < lo ? t0 : lo;  // wrap safe: 32-bit deltas relative to row 0
+      hi = t1 > hi ? t1 : hi;
+    }
   }
   const int lane = threadIdx.x & (bh::kWave - 1), wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < 3; ++k) v[k] = bh::wave_sum(v[k]);
+  if (want_span) {
 #pragma unroll
-  for (int off = bh::kWave / 2; off > 0; off >>= 1) {
-    const int olo = __shfl_down(lo, off, bh::kWave), ohi = __shfl_down(hi, off, bh::kWave);
-    lo = olo < lo ? olo : lo;
-    hi = ohi > hi ? ohi : hi;
+    for (int off = bh::kWave / 2; off > 0; off >>= 1) {
+      const int olo = __shfl_down(lo, off, bh::kWave), ohi = __shfl_down(hi, off, bh::kWave);
+      lo = olo < lo ? olo : lo;
+      hi = ohi > hi ? ohi : hi;
+    }
   }
   if (lane == 0) {
     lds[wave * 3 + 0] = v[0];
@@ -156,8 +161,9 @@ __device__ void gm_combine_rows(int kind, const double* __restrict__ partials, i
     lo = span_lds[w * 2] < lo ? span_lds[w * 2] : lo;
     hi = span_lds[w * 2 + 1] > hi ? span_lds[w * 2 + 1] : hi;
   }
-  const float span_ticks = (float)(hi - lo);
-  if (span_accum) {  // running sum / count for bench.py (works under hipGraph replay, no host involvement)
+  float span_ticks = 0.f;
+  if (want_span) {  // running sum / count for bench.py (works under hipGraph replay, no host involvement)
+    span_ticks = (float)(hi - lo);
     span_accum[0] += (double)span_ticks;
     span_accum[1] += 1.0;
   }

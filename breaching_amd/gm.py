@@ -91,8 +91,10 @@ class GradientMatchPlan:
             )
         # optional per-launch timing (bench.py): lists of (start, end) hipEvent pairs on the launch stream
         self.timers = None
-        # device-side running [sum of forward-launch spans in wall-clock ticks, launches]; bench.py zeroes / reads it
+        # device-side running [sum of forward-launch spans in wall-clock ticks, launches]: bench.py switches it on
+        # (`span_enabled`), zeroes and reads it; off by default -- it costs the finalize kernel two dependent loads
         self.span_accum = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.span_enabled = False
 
     def forward_span_us(self, reset=False):
         """Average span of the forward launches since the last reset, from the device wall clock (synchronises)."""
@@ -193,7 +195,7 @@ class GradientMatchPlan:
             _lib.check(lib.bh_event_record(ev0, stream), "bh_event_record")
         _lib.check(
             lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_rows, float(scale), float(tag_scale), float(fudge),
-                               _lib.ptr(stats), _lib.ptr(self.span_accum), stream),
+                               _lib.ptr(stats), _lib.ptr(self.span_accum if self.span_enabled else None), stream),
             "bh_gm_finalize",
         )
         if ev1 is not None:
@@ -216,6 +218,104 @@ class GradientMatchPlan:
 
     def split(self, grad_flat):
         return [grad_flat[o : o + n].view(s) for o, n, s in zip(self.flat_offsets, self.numels, self.shapes)]
+
+
+class ListLayout:
+    """Chunk table and packed layout for a list of tensors of given shapes (the multi-tensor elementwise kernels)."""
+
+    def __init__(self, shapes, device):
+        lib = _lib.load()
+        self.device = torch.device(device)
+        self.shapes = [tuple(s) for s in shapes]
+        self.n_tensors = len(self.shapes)
+        self.numels = [int(torch.Size(s).numel()) for s in self.shapes]
+        numel_arr = (c_int64 * self.n_tensors)(*self.numels)
+        n_chunks, flat_elems = c_int64(0), c_int64(0)
+        _lib.check(lib.bh_gm_table_size(self.n_tensors, numel_arr, ctypes.byref(n_chunks), ctypes.byref(flat_elems)), "bh_gm_table_size")
+        self.n_chunks, self.flat_elems = n_chunks.value, flat_elems.value
+        if self.n_chunks == 0:
+            raise ValueError("Tensor list holds no elements.")
+        chunks = (_lib.GmChunk * self.n_chunks)()
+        flat_off = (c_int64 * self.n_tensors)()
+        _lib.check(lib.bh_gm_build_table(self.n_tensors, numel_arr, chunks, self.n_chunks, flat_off), "bh_gm_build_table")
+        self.flat_offsets = list(flat_off)
+        self.mt_bounds = (c_int32 * (lib.bh_mt_num_groups(self.n_tensors) + 1))()
+        _lib.check(lib.bh_mt_group_bounds(self.n_tensors, chunks, self.n_chunks, self.mt_bounds), "bh_mt_group_bounds")
+        self.chunks_dev = torch.frombuffer(bytearray(bytes(chunks)), dtype=torch.uint8).to(self.device)
+        self._dummy = torch.zeros(4, dtype=torch.float32, device=self.device)
+
+    def matches(self, tensors):
+        return len(tensors) == self.n_tensors and all(tuple(t.shape) == s for t, s in zip(tensors, self.shapes))
+
+    def prepare(self, tensors, what):
+        """Contiguous, 16-byte aligned fp32 tensors (copies only when unavoidable)."""
+        out = []
+        for t in tensors:
+            _require_cuda(t, what)
+            if t.dtype != torch.float32:
+                raise NotImplementedError(f"HIP multi-tensor kernels compute in fp32; got {t.dtype}.")
+            if not t.is_contiguous():
+                t = t.contiguous()
+            if t.numel() and t.data_ptr() % 16:
+                t = t.clone(memory_format=torch.contiguous_format)
+            out.append(t)
+        return out
+
+    def pointers(self, tensors, nullable=False):
+        dummy = self._dummy.data_ptr()
+        return (c_void_p * self.n_tensors)(*[(0 if (t is None and nullable) else (t.data_ptr() if t.numel() else dummy)) for t in tensors])
+
+    def empty_flat(self):
+        return torch.empty(max(self.flat_elems, 4), dtype=torch.float32, device=self.device)
+
+    def split(self, flat):
+        return [flat[o : o + n].view(s) for o, n, s in zip(self.flat_offsets, self.numels, self.shapes)]
+
+
+class _LocalStepFunction(torch.autograd.Function):
+    """One local SGD step of the FedAvg unroll as a single node: (params, grads) -> params + alpha * grads [- base], all T
+    tensors in one launch (views of one packed buffer).  Backward: d/d params = identity, d/d grads = alpha (one launch)."""
+
+    @staticmethod
+    def forward(ctx, layout, alpha, with_base, *tensors):
+        lib = _lib.load()
+        T = layout.n_tensors
+        params = layout.prepare(tensors[:T], "parameter")
+        grads = layout.prepare(tensors[T : 2 * T], "step gradient")
+        base = layout.prepare(tensors[2 * T : 3 * T], "server parameter") if with_base else None
+        out = layout.empty_flat()
+        with torch.cuda.device(layout.device):
+            _lib.check(
+                lib.bh_mt_axpy(T, layout.pointers(params), layout.pointers(grads), layout.pointers(base) if with_base else None,
+                               float(alpha), _lib.ptr(layout.chunks_dev), layout.n_chunks, layout.mt_bounds, _lib.ptr(out),
+                               _lib.current_stream_handle(layout.device)),
+                "bh_mt_axpy",
+            )
+        ctx.layout, ctx.alpha, ctx.with_base = layout, float(alpha), with_base
+        return tuple(layout.split(out))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gouts):
+        lib = _lib.load()
+        layout, T = ctx.layout, ctx.layout.n_tensors
+        present = iter(layout.prepare([g for g in gouts if g is not None], "upstream gradient"))
+        gouts = [None if g is None else next(present) for g in gouts]
+        grad_params = list(gouts)  # identity
+        grad_grads = [None] * T
+        if any(ctx.needs_input_grad[3 + T : 3 + 2 * T]):
+            flat = layout.empty_flat()
+            with torch.cuda.device(layout.device):
+                _lib.check(
+                    lib.bh_mt_scale(T, layout.pointers(gouts, nullable=True), ctx.alpha, _lib.ptr(layout.chunks_dev), layout.n_chunks,
+                                    layout.mt_bounds, _lib.ptr(flat), _lib.current_stream_handle(layout.device)),
+                    "bh_mt_scale",
+                )
+            grad_grads = layout.split(flat)
+        grad_base = [None] * T if ctx.with_base else []
+        if ctx.with_base and any(ctx.needs_input_grad[3 + 2 * T :]):
+            grad_base = [None if g is None else -g for g in gouts]
+        return (None, None, None, *grad_params, *grad_grads, *grad_base)
 
 
 class _GradMatchFunction(torch.autograd.Function):
@@ -322,7 +422,9 @@ class HipGradientLoss(torch.nn.Module):
         gradient = torch.autograd.grad(task_loss, tuple(model.parameters()), create_graph=True)
         return gradient, task_loss
 
-    # objectives.py:48-72 (FedAvg unroll).  Plain torch ops via torch.func; fused kernels for it are a "next" row.
+    # objectives.py:48-72 (FedAvg unroll).  The functional forward / backward of each local step stay PyTorch; the
+    # parameter update of every step (`param - lr * grad` over the whole list) and the final `p_local - p_server` are one
+    # multi-tensor launch each (bh_mt_axpy), the last step fused with the difference.
     def _multi_step_update(self, model, candidate, labels):
         from torch.func import functional_call
 
@@ -330,18 +432,25 @@ class HipGradientLoss(torch.nn.Module):
         names = [n for n, _ in model.named_parameters()]
         server = [p for _, p in model.named_parameters()]
         buffers = dict(model.named_buffers())
-        params = [p.clone() for p in server]
         hp = self.local_hyperparams
+        layout = getattr(self, "_step_layout", None)
+        if layout is None or not layout.matches(server) or layout.device != server[0].device:
+            layout = self._step_layout = ListLayout([p.shape for p in server], server[0].device)
+        params = server
         seen = 0
         task_loss = None
-        for i in range(hp["steps"]):
+        steps = int(hp["steps"])
+        if steps < 1:
+            raise ValueError("local_hyperparams['steps'] must be at least 1.")
+        for i in range(steps):
             data = candidate[seen : seen + hp["data_per_step"]]
             seen = (seen + hp["data_per_step"]) % candidate.shape[0]
             step_labels = hp["labels"][i]
             task_loss = self.loss_fn(functional_call(model, ({**dict(zip(names, params)), **buffers},), (data,)), step_labels)
             step_grad = torch.autograd.grad(task_loss, params, create_graph=True)
-            params = [p - hp["lr"] * g for p, g in zip(params, step_grad)]
-        return [p_local - p_server for p_local, p_server in zip(params, server)], task_loss
+            last = i + 1 == steps
+            params = _LocalStepFunction.apply(layout, -float(hp["lr"]), last, *params, *step_grad, *(server if last else ()))
+        return list(params), task_loss  # after the last step: p_local - p_server
 
 
 class HipEuclidean(HipGradientLoss):

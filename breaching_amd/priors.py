@@ -327,24 +327,28 @@ class _LastLinearInput:
         self.handle.remove()
 
 
-class FeatureRegularization(torch.nn.Module):
+class HipFeatureRegularization(torch.nn.Module):
     """regularizers.py:23-60 -- match the input of the last linear layer to the features read off the observed gradient
-    (weight-gradient row / bias-gradient entry of each label).  Plain torch ops: a SURVEY section 8(f) "next" row, kept
-    so that `modern.yaml` / `legacy.yaml` style configs construct and run; it rides the autograd path of the fused loop."""
+    (weight-gradient row / bias-gradient entry of each label).  value = scale * mean((features - measured)^2) and its
+    gradient run through kernel A's euclidean reduction (0.5 * s' * sum (r - d)^2 with s' = 2 * scale / numel) on the
+    one-tensor list [features]: forward, finalize and backward are one launch each, the measured features are packed once."""
 
     def __init__(self, setup, scale=0.1):
         super().__init__()
         self.setup = setup
         self.scale = scale
         self.refs = []
+        self._objectives = []
 
     def initialize(self, models, shared_data, labels, *args, **kwargs):
+        from .gm import HipEuclidean
+
         self.measured_features = []
         for user_data in shared_data:
             weights, bias = user_data["gradients"][-2], user_data["gradients"][-1]
             debiased = weights / bias[:, None]
             rows = [debiased[label] if bias[label] != 0 else torch.zeros_like(debiased[0]) for label in labels]
-            self.measured_features.append(torch.stack(rows))
+            self.measured_features.append(torch.stack(rows).contiguous())
         for ref in self.refs:
             if ref is not None:
                 ref.close()
@@ -356,6 +360,11 @@ class FeatureRegularization(torch.nn.Module):
                     last = module
             if last is not None:
                 self.refs[idx] = _LastLinearInput(last)
+        self._objectives = []
+        for measured in self.measured_features:
+            objective = HipEuclidean(scale=2.0 * self.scale / max(measured.numel(), 1))
+            objective.initialize(None, _NoMixedPrecision, None)
+            self._objectives.append(objective)
 
     def release_graph(self):
         for ref in self.refs:
@@ -364,17 +373,50 @@ class FeatureRegularization(torch.nn.Module):
 
     def forward(self, tensor, *args, **kwargs):
         value = 0
-        for ref, measured in zip(self.refs, self.measured_features):
-            value = value + (ref.features - measured).pow(2).mean()
-        return value * self.scale
+        for ref, measured, objective in zip(self.refs, self.measured_features, self._objectives):
+            features = ref.features
+            if features.shape != measured.shape:  # broadcasting cases of the reference formula: keep the plain ops
+                value = value + (features - measured).pow(2).mean() * self.scale
+            else:
+                value = value + objective.gradient_based_loss([features], [measured]).squeeze(0)
+        return value
 
     def __repr__(self):
-        return f"Feature space regularization, scale={self.scale}"
+        return f"Feature space regularization, scale={self.scale} [HIP gfx950]"
 
 
-class OrthogonalityRegularization(torch.nn.Module):
-    """regularizers.py:156-181 -- mean squared pairwise products between batch entries (the reference does not apply
-    `scale` to the value; kept)."""
+class _NoMixedPrecision:
+    mixed_precision = False
+
+
+class _OrthogonalityFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("HIP orthogonality prior needs an fp32 tensor on a ROCm device (no CPU fallback).")
+        xc = x.detach().contiguous()
+        B = xc.shape[0]
+        D = xc.numel() // B
+        grad = torch.empty_like(xc)
+        partials = torch.empty(_lib.BH_PRIOR_MAX_GRID, dtype=torch.float64, device=xc.device)
+        with torch.cuda.device(xc.device):
+            grid = _lib.check(lib.bh_prior_orthogonality(_lib.ptr(xc), B, D, _lib.ptr(grad), _lib.ptr(partials),
+                                                         _lib.current_stream_handle(xc.device)), "bh_prior_orthogonality")
+        ctx.save_for_backward(grad)
+        ctx.in_shape = x.shape
+        return partials[:grid].sum().to(torch.float32)  # fixed-order fp64 combine of the per-workgroup values
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return (grad * gout).view(ctx.in_shape)
+
+
+class HipOrthogonalityRegularization(torch.nn.Module):
+    """regularizers.py:156-181 -- sum over ordered pairs i != j of the batch of mean_k (x_ik x_jk)^2, value and analytic
+    gradient in one pass (the reference does not apply `scale` to the value; kept)."""
 
     def __init__(self, setup, scale=0.1):
         super().__init__()
@@ -387,22 +429,51 @@ class OrthogonalityRegularization(torch.nn.Module):
     def forward(self, tensor, *args, **kwargs):
         if tensor.shape[0] == 1:
             return 0
-        B = tensor.shape[0]
-        products = (tensor.unsqueeze(0) * tensor.unsqueeze(1)).pow(2).view(B, B, -1).mean(dim=2)
-        idx = torch.arange(0, B, device=tensor.device)
-        products[idx, idx] = 0
-        return products.sum()
+        return _OrthogonalityFunction.apply(tensor)
 
     def __repr__(self):
-        return f"Input Orthogonality, scale={self.scale}"
+        return f"Input Orthogonality, scale={self.scale} [HIP gfx950]"
 
 
-# regularizers.py:233-239.  TV / norm / DeepInversion run on the HIP kernels; `features` and `orthogonality` are
-# SURVEY section 8(f) "next" rows implemented with plain torch ops for drop-in completeness.
+def psnr_on_device(reconstruction, reference, mean=None, std=None, factor=1.0, clip=True):
+    """PSNR per example of a normalised reconstruction batch against the ground truth, computed on the GPU
+    (analysis/metrics.py:108-130 with the de-normalisation and clamp of analysis.py:228-229 folded in).
+    Returns a float32 tensor [2 + B]: mean, max, per-example values; no host synchronisation."""
+    lib = _lib.load()
+    if not reconstruction.is_cuda or reconstruction.dtype != torch.float32:
+        raise RuntimeError("psnr_on_device needs fp32 tensors on a ROCm device (no CPU fallback).")
+    rec = reconstruction.detach().contiguous()
+    ref = reference.detach().to(device=rec.device, dtype=torch.float32).contiguous()
+    if rec.shape != ref.shape:
+        raise ValueError(f"Shape mismatch: {tuple(rec.shape)} vs {tuple(ref.shape)}.")
+    B = rec.shape[0]
+    per_example = rec.numel() // B
+    P = _lib.PsnrParams()
+    channels = 1
+    if mean is not None:
+        mean = torch.as_tensor(mean).flatten().tolist()
+        std = torch.as_tensor(std).flatten().tolist()
+        channels = len(mean)
+        if channels > 4 or rec.dim() < 2 or rec.shape[1] != channels:
+            raise ValueError("mean / std must have one entry per channel (at most 4).")
+    for c in range(4):
+        P.mean[c] = mean[c] if mean is not None and c < channels else 0.0
+        P.std[c] = std[c] if std is not None and c < channels else 1.0
+    P.factor, P.clip = float(factor), int(bool(clip))
+    plane = per_example // channels
+    mse = torch.empty(B, dtype=torch.float64, device=rec.device)
+    out = torch.empty(2 + B, dtype=torch.float32, device=rec.device)
+    with torch.cuda.device(rec.device):
+        _lib.check(lib.bh_metric_psnr(_lib.ptr(rec), _lib.ptr(ref), B, per_example, plane, channels, P, _lib.ptr(mse), _lib.ptr(out),
+                                      _lib.current_stream_handle(rec.device)), "bh_metric_psnr")
+    return out
+
+
+# regularizers.py:233-239 -- every regulariser runs on the HIP kernels.
 regularizer_lookup = dict(
     total_variation=HipTotalVariation,
-    orthogonality=OrthogonalityRegularization,
+    orthogonality=HipOrthogonalityRegularization,
     norm=HipNormRegularization,
     deep_inversion=HipDeepInversion,
-    features=FeatureRegularization,
+    features=HipFeatureRegularization,
 )

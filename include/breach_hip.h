@@ -126,9 +126,10 @@ int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
                    float* stats_dev, double* span_accum_dev, void* stream);
 /* Every forward workgroup stamps the constant-rate device wall clock (bh_wall_clock_khz) on entry and exit into the
- * spare word of its partial row; the finalize kernel reduces them to the launch's span (stats[BH_GM_STAT_SPAN_TICKS])
- * and, when `span_accum_dev` is non-NULL, adds it to span_accum_dev[0] and 1 to span_accum_dev[1] (doubles).  This is how
- * bench.py times kernel A *inside* hipGraph replays, where host-visible event pairs cannot be placed. */
+ * spare word of its partial row; when `span_accum_dev` is non-NULL the finalize kernel reduces them to the launch's
+ * span (stats[BH_GM_STAT_SPAN_TICKS]) and adds it to span_accum_dev[0] and 1 to span_accum_dev[1] (doubles).  This is
+ * how bench.py times kernel A *inside* hipGraph replays, where host-visible event pairs cannot be placed; the product
+ * path passes NULL (stats[BH_GM_STAT_SPAN_TICKS] = 0). */
 int32_t bh_wall_clock_khz(void);
 
 /* Backward: d objective / d rec_i for every tensor, written into the packed layout `grad_flat` (same offsets as
@@ -222,6 +223,54 @@ int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double
 int bh_bn_bwd(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
               const bh_bn_item* bwd_items_dev, int64_t n_bwd_items, const float* coef_dev, const float* gout_dev,
               float* grad_flat, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Multi-tensor elementwise kernels over per-parameter lists (FedAvg unroll, Pearlmutter offset) and batch kernels
+ * ---------------------------------------------------------------------------------------------------------------- */
+
+/* Pointers per operand list and launch (three lists travel in the kernel arguments). */
+#define BH_MT_MAX_PTRS 128
+int32_t bh_mt_num_groups(int32_t n_tensors);
+/* Like bh_gm_group_bounds for launch groups of BH_MT_MAX_PTRS tensors: group_chunk_begin[bh_mt_num_groups + 1]. */
+int bh_mt_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_t n_chunks, int32_t* group_chunk_begin);
+
+/* out = a + alpha * b            (c_ptrs == NULL)      one local SGD step of the FedAvg unroll, alpha = -lr
+ * out = (a + alpha * b) - c      (c_ptrs != NULL)      the last step fused with `p_local - p_server`
+ * for every tensor of the list, written into the packed layout of the chunk table (same as bh_gm_pack); mul, add and
+ * sub round separately, exactly like torch's `param - lr * grad` and `p_local - p_server`.  Host arrays of device
+ * pointers, each tensor contiguous fp32 and 16-byte aligned.
+ * reference: objectives.py:64-69 (`params = [param - lr * grad ...]`, `gradient = [p_local - p_server ...]`). */
+int bh_mt_axpy(int32_t n_tensors, const void* const* a_ptrs, const void* const* b_ptrs, const void* const* c_ptrs,
+               float alpha, const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
+               float* out_flat, void* stream);
+/* out = alpha * a; a NULL entry of a_ptrs reads as zeros.  The backward of bh_mt_axpy with respect to b. */
+int bh_mt_scale(int32_t n_tensors, const void* const* a_ptrs, float alpha, const bh_gm_chunk* chunks_dev, int64_t n_chunks,
+                const int32_t* group_chunk_begin, float* out_flat, void* stream);
+/* out = theta + (coef[0] * data + coef[1] * grad): the model parameters offset along the first-order direction of the
+ * gradient-matching objective, coefficients read from the device (the finalize kernel writes them at
+ * stats[BH_GM_STAT_PATCH_D .. BH_GM_STAT_PATCH_R], already multiplied by the finite-difference step).
+ * reference: objectives.py:347-352 (`torch._foreach_add_(model.parameters(), first_order_grad, alpha=eps_n)`), :468-486. */
+int bh_mt_patch(int32_t n_tensors, const void* const* theta_ptrs, const void* const* grad_ptrs, const float* data_flat,
+                const float* coef_dev, const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
+                float* out_flat, void* stream);
+
+/* OrthogonalityRegularization on x[B, D] (D = C*H*W): value = sum over ordered pairs i != j of mean_k (x_ik * x_jk)^2
+ * (the reference does not apply `scale`), analytic gradient into grad_out[B, D], per-workgroup partial values into
+ * partials_dev[BH_PRIOR_MAX_GRID].  Returns the grid size (> 0) or a negative error.
+ * reference: regularizers.py:156-181. */
+int bh_prior_orthogonality(const float* x, int32_t B, int64_t D, float* grad_out, double* partials_dev, void* stream);
+
+typedef struct bh_psnr_params {
+  float mean[4]; /* de-normalisation: img = x * std[c] + mean[c]  (analysis.py:228-229) */
+  float std[4];
+  float factor;  /* peak value (1.0) */
+  int32_t clip;  /* clamp both images to [0, 1] first */
+} bh_psnr_params;
+/* PSNR of rec[B, per_example] against ref (both normalised like the candidate): out_dev[0] = mean over examples,
+ * out_dev[1] = max, out_dev[2 + b] = example b; +inf when an example matches exactly, NaN for a non-finite error.
+ * mse_dev: B doubles of workspace.  reference: analysis/metrics.py:108-130 (psnr_compute, batched=False). */
+int bh_metric_psnr(const float* rec, const float* ref, int32_t B, int64_t per_example, int64_t plane, int32_t channels,
+                   const bh_psnr_params* params, double* mse_dev, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Trial state, loss commit and the fused candidate step ("kernel B")

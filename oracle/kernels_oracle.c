@@ -207,3 +207,60 @@ void oracle_candidate_step(int64_t n, int64_t plane, int channels, double* x, co
     }
   }
 }
+
+/*
+ * OrthogonalityRegularization on x[B, D] (regularizers.py:170-178): full_products[i][j] = mean_k (x_ik * x_jk)^2, diagonal
+ * zeroed, summed over all ordered pairs.  grad (nullable) = d value / d x.
+ */
+double oracle_orthogonality(const float* x, int B, int64_t D, double* grad) {
+  double value = 0;
+  for (int i = 0; i < B; ++i)
+    for (int j = 0; j < B; ++j) {
+      if (i == j) continue;
+      double acc = 0;
+      for (int64_t k = 0; k < D; ++k) {
+        double p = (double)x[(int64_t)i * D + k] * (double)x[(int64_t)j * D + k];
+        acc += p * p;
+      }
+      value += acc / (double)D;
+    }
+  if (grad) {
+    for (int i = 0; i < B; ++i)
+      for (int64_t k = 0; k < D; ++k) {
+        double others = 0;
+        for (int j = 0; j < B; ++j)
+          if (j != i) others += (double)x[(int64_t)j * D + k] * (double)x[(int64_t)j * D + k];
+        /* the pair (i, j) and the pair (j, i) both contain x_ik: 2 * 2 x_ik x_jk^2 / D */
+        grad[(int64_t)i * D + k] = 4.0 * (double)x[(int64_t)i * D + k] * others / (double)D;
+      }
+  }
+  return value;
+}
+
+/*
+ * PSNR per example (analysis/metrics.py:117-130, batched=False) of de-normalised, optionally clamped images
+ * (analysis.py:228-229): img = x * std[c] + mean[c].  out[0] = mean, out[1] = max, out[2 + b] = example b.
+ */
+void oracle_psnr(const float* rec, const float* ref, int B, int64_t per_example, int64_t plane, int channels,
+                 const double* mean, const double* std, double factor, int clip, double* out) {
+  double sum = 0, best = -INFINITY;
+  for (int b = 0; b < B; ++b) {
+    double acc = 0;
+    for (int64_t i = 0; i < per_example; ++i) {
+      int c = channels > 1 ? (int)((i / plane) % channels) : 0;
+      double u = (double)rec[(int64_t)b * per_example + i] * std[c] + mean[c];
+      double v = (double)ref[(int64_t)b * per_example + i] * std[c] + mean[c];
+      if (clip) {
+        u = u < 0 ? 0 : (u > 1 ? 1 : u);
+        v = v < 0 ? 0 : (v > 1 ? 1 : v);
+      }
+      acc += (u - v) * (u - v);
+    }
+    double p = 10.0 * log10(factor * factor / (acc / (double)per_example));
+    out[2 + b] = p;
+    sum += p;
+    if (p > best) best = p;
+  }
+  out[0] = sum / B;
+  out[1] = best;
+}

@@ -30,6 +30,11 @@ def load_oracle():
                                               POINTER(c_double), POINTER(c_double), c_double, c_double, c_double, c_double,
                                               c_double, c_int, c_int, c_int, c_int, c_int, c_double, c_double, c_int,
                                               POINTER(c_double), POINTER(c_double)]
+        lib.oracle_orthogonality.restype = c_double
+        lib.oracle_orthogonality.argtypes = [POINTER(c_float), c_int, c_int64, POINTER(c_double)]
+        lib.oracle_psnr.restype = None
+        lib.oracle_psnr.argtypes = [POINTER(c_float), POINTER(c_float), c_int, c_int64, c_int64, c_int, POINTER(c_double),
+                                    POINTER(c_double), c_double, c_int, POINTER(c_double)]
         _LIB = lib
     return _LIB
 
@@ -111,3 +116,31 @@ def candidate_step(x, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, weigh
                               eps, weight_decay, int(decoupled), int(step), int(sign_mode), int(iteration), int(max_iterations),
                               float(langevin), float(clip), int(boxed), _dp(lo_a), _dp(hi_a))
     return x, m, v
+
+
+def orthogonality(x):
+    """Value and gradient (fp64) of OrthogonalityRegularization on x[B, ...] (regularizers.py:170-178)."""
+    lib = load_oracle()
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    B = x.shape[0]
+    D = x.size // B
+    grad = np.zeros(x.size, dtype=np.float64)
+    value = lib.oracle_orthogonality(_fp(x), B, D, _dp(grad))
+    return value, grad.reshape(x.shape)
+
+
+def psnr(rec, ref, mean=None, std=None, factor=1.0, clip=True):
+    """[mean, max, per-example...] PSNR (analysis/metrics.py:117-130) of normalised batches rec / ref [B, C, ...]."""
+    lib = load_oracle()
+    rec = np.ascontiguousarray(rec, dtype=np.float32)
+    ref = np.ascontiguousarray(ref, dtype=np.float32)
+    B = rec.shape[0]
+    per_example = rec.size // B
+    channels = 1 if mean is None else len(mean)
+    m = np.zeros(4, dtype=np.float64)
+    s = np.ones(4, dtype=np.float64)
+    if mean is not None:
+        m[:channels], s[:channels] = np.asarray(mean, dtype=np.float32), np.asarray(std, dtype=np.float32)
+    out = np.zeros(2 + B, dtype=np.float64)
+    lib.oracle_psnr(_fp(rec), _fp(ref), B, per_example, per_example // channels, channels, _dp(m), _dp(s), float(factor), int(clip), _dp(out))
+    return out

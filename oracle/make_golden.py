@@ -148,6 +148,24 @@ def golden_kernels():
         (g,) = torch.autograd.grad(value, x)
         out[f"bn_{tag}__x"], out[f"bn_{tag}__rm"], out[f"bn_{tag}__rv"] = feat, bn.running_mean.numpy().copy(), bn.running_var.numpy().copy()
         out[f"bn_{tag}__value"], out[f"bn_{tag}__grad"] = value.detach().numpy().reshape(-1), g.numpy()
+    # orthogonality regulariser (regularizers.py:156-181) and the PSNR metric (analysis/metrics.py:108-130) -- drawn last so
+    # that the vectors above keep their values
+    from breaching.analysis import metrics as M
+
+    xo = rng.standard_normal((4, 3, 9, 11)).astype(np.float32)
+    out["orth_x"] = xo
+    x = torch.tensor(xo, requires_grad=True)
+    value = R.OrthogonalityRegularization(setup, scale=0.1)(x)
+    (g,) = torch.autograd.grad(value, x)
+    out["orth__value"], out["orth__grad"] = value.detach().numpy().reshape(-1), g.numpy()
+    mean, std = np.asarray([0.485, 0.456, 0.406], dtype=np.float32), np.asarray([0.229, 0.224, 0.225], dtype=np.float32)
+    truth = (rng.random((3, 3, 10, 7)).astype(np.float32) - mean[None, :, None, None]) / std[None, :, None, None]
+    recon = truth + rng.standard_normal(truth.shape).astype(np.float32) * np.asarray([0.05, 0.5, 3.0], dtype=np.float32)[:, None, None, None]
+    dm, ds = torch.tensor(mean)[None, :, None, None], torch.tensor(std)[None, :, None, None]
+    rec_denorm = torch.clamp(torch.tensor(recon) * ds + dm, 0, 1)  # analysis.py:228-229
+    gt_denorm = torch.clamp(torch.tensor(truth) * ds + dm, 0, 1)
+    avg, best = M.psnr_compute(rec_denorm, gt_denorm, factor=1)
+    out.update(psnr_rec=recon, psnr_truth=truth, psnr_mean=mean, psnr_std=std, psnr__avg_max=np.asarray([avg, best], dtype=np.float64))
     np.savez_compressed(os.path.join(GOLDEN, "kernels.npz"), **out)
 
 
@@ -344,6 +362,12 @@ def golden_fedavg():
     out = _attack_record(cfg, case, x0, rec, stats)
     twins, twin_psnr, twin_opt = _twin_runs(cfg, case, x0, 2)
     out.update(twin_history=twins, twin_psnr=twin_psnr, twin_opt_value=twin_opt)
+    # plain Adam (no sign at all), smaller step: a smooth trajectory, strict tolerance over the whole horizon
+    cfg = _cfg("invertinggradients", ["optim.max_iterations=30", "optim.callback=10", "optim.signed=null", "optim.step_size=0.01"])
+    rec, stats = _run_reference_attack(cfg, case, x0)
+    out.update({f"plain_{k}": v for k, v in _attack_record(cfg, case, x0, rec, stats).items()})
+    twins, twin_psnr, twin_opt = _twin_runs(cfg, case, x0, 2)
+    out.update(plain_twin_history=twins, plain_twin_psnr=twin_psnr, plain_twin_opt_value=twin_opt)
     np.savez_compressed(os.path.join(GOLDEN, "attack_fedavg.npz"), **out)
 
 

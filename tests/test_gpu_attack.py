@@ -322,7 +322,8 @@ def test_tag_joint_attack_on_bert(golden_dir):
 
 def test_legacy_family_softsign_opponent_tv_features_deepinversion(golden_dir):
     """`legacy.yaml` family on a 2-image ConvNet case: soft sign, double-opponent TV with p=2 / q=0.5 (general stencil
-    path), feature regulariser (torch ops on the autograd path), DeepInversion prior (kernel D), cosine decay."""
+    path), feature regulariser (kernel A's euclidean reduction on the last linear layer's input), DeepInversion prior
+    (kernel D), cosine decay."""
     from breaching_amd import get_attack_config
     from breaching_amd.cases import build_case, initial_candidate
 
@@ -331,7 +332,7 @@ def test_legacy_family_softsign_opponent_tv_features_deepinversion(golden_dir):
     x0 = initial_candidate(case.data_cfg, 2, seed=6)
     cfg = get_attack_config("legacy", ["optim.max_iterations=30", "optim.callback=10", "regularization.deep_inversion.scale=0.001"])
     rec, stats, attacker = _attack(case, cfg, x0)
-    assert [type(r).__name__ for r in attacker.regularizers] == ["HipTotalVariation", "FeatureRegularization", "HipDeepInversion"]
+    assert [type(r).__name__ for r in attacker.regularizers] == ["HipTotalVariation", "HipFeatureRegularization", "HipDeepInversion"]
     _check_against_golden("legacy_", gold, rec, stats, case)
 
 
@@ -351,8 +352,9 @@ def test_wei_family_lbfgs_generic_loop(golden_dir):
 
 
 def test_fedavg_multi_step_objective(golden_dir):
-    """FedAvg user update (2 local SGD steps x 2 images): `_grad_fn_multi_step` (objectives.py:48-72) unrolled with
-    torch.func on our side, matched against the reference's make_functional implementation."""
+    """FedAvg user update (2 local SGD steps x 2 images): `_grad_fn_multi_step` (objectives.py:48-72); every local step's
+    parameter update and the final `p_local - p_server` are one multi-tensor launch each (bh_mt_axpy), matched against the
+    reference's make_functional implementation."""
     from breaching_amd import get_attack_config
     from breaching_amd.cases import build_fedavg_case, initial_candidate
 
@@ -363,6 +365,12 @@ def test_fedavg_multi_step_objective(golden_dir):
     rec, stats, _ = _attack(case, cfg, x0)
     assert rec["data"].shape == (4, 3, 32, 32)
     _check_against_golden("", gold, rec, stats, case)
+    # plain Adam, no sign: the smoothest setting the unroll can be driven in (the reference's own twins still part by 5e-4
+    # within five iterations -- max-pool / ReLU kinks inside two chained local steps)
+    cfg = get_attack_config("invertinggradients", ["optim.max_iterations=30", "optim.callback=10", "optim.signed=null",
+                                                   "optim.step_size=0.01"])
+    rec, stats, _ = _attack(case, cfg, x0)
+    _check_against_golden("plain_", gold, rec, stats, case)
 
 
 def test_trials_in_flight_match_sequential_trials():

@@ -419,3 +419,81 @@ def test_plan_is_never_reused_for_another_gradient_list(hip_lib):
     assert loss_for(strided) == pytest.approx(want_strided, rel=1e-5)
     obj.initialize(None, type("I", (), dict(mixed_precision=False))(), None)
     assert obj._plans == []
+
+
+def test_orthogonality_prior_matches_reference_golden_and_c_oracle(golden_dir, kernels_oracle, hip_lib):
+    from breaching_amd.priors import HipOrthogonalityRegularization
+    from oracle import kernels_ref
+
+    gold = np.load(os.path.join(golden_dir, "kernels.npz"))
+    reg = HipOrthogonalityRegularization(dict(device=_dev(), dtype=torch.float), scale=0.1)
+    x = torch.tensor(gold["orth_x"], device=_dev(), requires_grad=True)
+    value = reg(x)
+    (g,) = torch.autograd.grad(value * 2.0, x)
+    want = float(gold["orth__value"][0])
+    assert abs(value.item() - want) <= 5e-6 * abs(want)
+    _assert_grads([g.cpu().numpy()], [2.0 * gold["orth__grad"].astype(np.float64)], rtol=2e-5)
+    assert reg(x[:1]) == 0  # a single example has no pairs (regularizers.py:171-172)
+    rng = np.random.default_rng(41)
+    x_np = rng.standard_normal((8, 3, 64, 50)).astype(np.float32)  # D = 9600: several workgroups, grid-stride tail
+    x = torch.tensor(x_np, device=_dev(), requires_grad=True)
+    value = reg(x)
+    (g,) = torch.autograd.grad(value, x)
+    want_v, want_g = kernels_ref.orthogonality(x_np)
+    assert abs(value.item() - want_v) <= 2e-6 * abs(want_v)
+    _assert_grads([g.cpu().numpy()], [want_g], rtol=1e-5)
+
+
+def test_psnr_on_device_matches_reference_golden_and_c_oracle(golden_dir, kernels_oracle, hip_lib):
+    from breaching_amd.priors import psnr_on_device
+    from oracle import kernels_ref
+
+    gold = np.load(os.path.join(golden_dir, "kernels.npz"))
+    rec, truth = torch.tensor(gold["psnr_rec"], device=_dev()), torch.tensor(gold["psnr_truth"], device=_dev())
+    out = psnr_on_device(rec, truth, gold["psnr_mean"], gold["psnr_std"]).cpu().numpy()
+    np.testing.assert_allclose(out[:2], gold["psnr__avg_max"], rtol=5e-6)
+    want = kernels_ref.psnr(gold["psnr_rec"], gold["psnr_truth"], gold["psnr_mean"], gold["psnr_std"])
+    np.testing.assert_allclose(out, want, rtol=5e-6)
+    # full-size batch, no clamp, no de-normalisation; identical image -> +inf, NaN input -> NaN (metrics.py:122-130)
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((4, 3, 224, 224)).astype(np.float32)
+    b = a + rng.standard_normal(a.shape).astype(np.float32) * 0.1
+    out = psnr_on_device(torch.tensor(a, device=_dev()), torch.tensor(b, device=_dev()), clip=False).cpu().numpy()
+    np.testing.assert_allclose(out, kernels_ref.psnr(a, b, clip=False), rtol=5e-6)
+    b[1] = a[1]
+    assert np.isinf(psnr_on_device(torch.tensor(a, device=_dev()), torch.tensor(b, device=_dev()), clip=False)[0].item())
+    b[1, 0, 0, 0] = np.nan
+    assert np.isnan(psnr_on_device(torch.tensor(a, device=_dev()), torch.tensor(b, device=_dev()), clip=False)[0].item())
+
+
+def test_multi_tensor_axpy_scale_and_fedavg_step_function(hip_lib):
+    """bh_mt_axpy / bh_mt_scale against torch, bit for bit (mul, add and sub round separately like torch's ops), over a ragged
+    list longer than one launch group (> 128 tensors), through the autograd node the FedAvg unroll uses."""
+    from breaching_amd.gm import ListLayout, _LocalStepFunction
+
+    gen = torch.Generator().manual_seed(9)
+    shapes = [(5000,), (3,), (4096,), (33, 65), (1,), (2, 4100)] + [(50 + i,) for i in range(140)]
+    layout = ListLayout(shapes, _dev())
+    assert hip_lib.bh_mt_num_groups(len(shapes)) == 2
+    params = [torch.randn(s, generator=gen).to(_dev()).requires_grad_(True) for s in shapes]
+    grads = [torch.randn(s, generator=gen).to(_dev()).requires_grad_(True) for s in shapes]
+    base = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
+    lr = 0.0371
+    out = _LocalStepFunction.apply(layout, -lr, False, *params, *grads)
+    for o, p, g in zip(out, params, grads):
+        assert torch.equal(o, p.detach() - lr * g.detach())  # objectives.py:67
+    out2 = _LocalStepFunction.apply(layout, -lr, True, *params, *grads, *base)
+    for o, p, g, b in zip(out2, params, grads, base):
+        assert torch.equal(o, (p.detach() - lr * g.detach()) - b)  # :70
+    # backward: identity to the parameters, -lr to the gradients; outputs without upstream gradient count as zero
+    ups = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
+    used = [i for i in range(len(shapes)) if i % 3 != 1]
+    loss = sum((out2[i] * ups[i]).sum() for i in used)
+    got = torch.autograd.grad(loss, params + grads, allow_unused=True)
+    for i in range(len(shapes)):
+        gp, gg = got[i], got[len(shapes) + i]
+        if i in used:
+            assert torch.equal(gp, ups[i]) and torch.equal(gg, -lr * ups[i])
+        else:
+            assert gp is None or float(gp.abs().max()) == 0.0
+            assert gg is None or float(gg.abs().max()) == 0.0

@@ -92,6 +92,26 @@ def test_c_oracle_bn_statistic(tag, golden_dir, kernels_oracle):
     assert float(np.abs(grad - gold[f"bn_{tag}__grad"]).max()) <= 2e-5 * _peak([gold[f"bn_{tag}__grad"]])
 
 
+def test_c_oracle_orthogonality_and_psnr(golden_dir, kernels_oracle):
+    """regularizers.py:156-181 and analysis/metrics.py:108-130 (with the de-normalisation / clamp of analysis.py:228-229)."""
+    from breaching_amd.cases import psnr as cases_psnr
+    from oracle import kernels_ref
+
+    gold = _gold(golden_dir, "kernels.npz")
+    value, grad = kernels_ref.orthogonality(gold["orth_x"])
+    want = float(gold["orth__value"][0])
+    assert abs(value - want) <= 5e-6 * abs(want)
+    assert float(np.abs(grad - gold["orth__grad"]).max()) <= 1e-5 * _peak([gold["orth__grad"]])
+    out = kernels_ref.psnr(gold["psnr_rec"], gold["psnr_truth"], gold["psnr_mean"], gold["psnr_std"], clip=True)
+    np.testing.assert_allclose(out[:2], gold["psnr__avg_max"], rtol=2e-6)
+    assert out[1] == out[2:].max() and out[0] == pytest.approx(out[2:].mean())
+    # the host-side metric the parity tests use agrees with the reference's as well
+    from breaching_amd.config import AttrDict
+
+    data_cfg = AttrDict(mean=gold["psnr_mean"].tolist(), std=gold["psnr_std"].tolist())
+    assert cases_psnr(torch.tensor(gold["psnr_rec"]), torch.tensor(gold["psnr_truth"]), data_cfg) == pytest.approx(float(gold["psnr__avg_max"][0]), rel=2e-6)
+
+
 def test_c_oracle_candidate_step_against_torch_adam(kernels_oracle):
     """The Adam part is torch.optim (third-party arithmetic); the step oracle must track it to fp32 rounding."""
     from oracle import kernels_ref
