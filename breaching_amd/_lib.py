@@ -16,7 +16,7 @@ BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
 BH_GM_MAX_ROWS = 2048
 BH_GM_DEFAULT_ROWS = 512
-BH_GM_STAT_WORDS = 8
+BH_GM_STAT_WORDS = 12
 BH_PRIOR_MAX_GRID = 1024
 BH_BN_MAX_LAYERS = 448
 BH_MT_MAX_PTRS = 128
@@ -33,7 +33,9 @@ GM_KINDS = {
     "euclidean": 4,
     "l1": 5,
     "tag-euclidean": 6,
+    "pearlmutter-loss": 7,
 }
+GM_STAT_PATCH_D, GM_STAT_PATCH_R, GM_STAT_FD_STEP, GM_STAT_FD_SCALE = 8, 9, 10, 11
 STATE_IT, STATE_DEAD, STATE_FIRST_BAD, STATE_IMPROVED, STATE_MIN, STATE_TOTAL, STATE_GNORM = range(7)
 SIGN_NONE, SIGN_HARD, SIGN_SOFT = 0, 1, 2
 
@@ -90,7 +92,7 @@ _PROTOTYPES = {
     ),
     "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32)]),
     "bh_gm_set_rows_cap": (c_int32, [c_int32]),
-    "bh_gm_finalize": (c_int, [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "bh_gm_finalize": (c_int, [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "bh_wall_clock_khz": (c_int32, []),
     "bh_gm_bwd": (
         c_int,
@@ -128,7 +130,8 @@ _PROTOTYPES = {
     "bh_mt_scale": (c_int, [c_int32, POINTER(c_void_p), c_float, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p]),
     "bh_mt_patch": (
         c_int,
-        [c_int32, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p],
+        [c_int32, POINTER(c_void_p), POINTER(c_void_p), c_void_p, c_void_p, c_float, c_void_p, c_int64, POINTER(c_int32), c_void_p,
+         c_void_p],
     ),
     "bh_prior_orthogonality": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     "bh_metric_psnr": (

@@ -124,12 +124,30 @@ class ResNet(torch.nn.Module):
         return self.linear(torch.flatten(self.avgpool(x), 1))
 
 
+class SmoothNet(torch.nn.Module):
+    """Small kink-free classifier (softplus, average pooling): finite differences of its gradients are meaningful, which the
+    parity tests of the Pearlmutter objectives need (on ReLU / max-pool nets the finite difference is dominated by kinks)."""
+
+    def __init__(self, width=16, num_classes=10, num_channels=3):
+        super().__init__()
+        self.features = torch.nn.Sequential(
+            torch.nn.Conv2d(num_channels, width, 3, padding=1), torch.nn.Softplus(), torch.nn.AvgPool2d(2),
+            torch.nn.Conv2d(width, 2 * width, 3, padding=1), torch.nn.Softplus(), torch.nn.AvgPool2d(2),
+            torch.nn.Conv2d(2 * width, 2 * width, 3, padding=1), torch.nn.Softplus(), torch.nn.AdaptiveAvgPool2d(2))
+        self.head = torch.nn.Linear(8 * width, num_classes)
+
+    def forward(self, x):
+        return self.head(torch.flatten(self.features(x), 1))
+
+
 def build_model(name, num_classes, seed=0):
     """Seeded random-init victim model in eval mode (public BN buffers: mean 0, var 1)."""
     torch.manual_seed(seed)
     key = name.lower()
     if key == "convnet":
         model = ConvNet(width=64, num_classes=num_classes)
+    elif key == "smoothnet":
+        model = SmoothNet(num_classes=num_classes)
     elif key.startswith("resnet"):
         model = ResNet(depth=int(key.replace("resnet", "")), num_classes=num_classes)
     else:

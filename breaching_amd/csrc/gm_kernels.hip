@@ -46,6 +46,10 @@ __device__ __forceinline__ void accumulate(float r, float d, float& a0, float& a
     a0 = fmaf(r, d, a0);
     a1 = fmaf(r, r, a1);
     a2 = fmaf(d, d, a2);
+  } else if constexpr (KIND == BH_GM_PEARL_L2) {
+    const float e = r - d;
+    a0 = fmaf(e, e, a0);  // residual norm (the objective)
+    a1 = fmaf(r, r, a1);  // |grad|^2 (the finite-difference step adapts to it, objectives.py:346)
   } else {
     const float e = r - d;
     if constexpr (KIND != BH_GM_L1) a0 = fmaf(e, e, a0);
@@ -62,10 +66,13 @@ __device__ __forceinline__ void accumulate4(const float4& r, const float4& d, fl
 }
 
 // Objective epilogue on the three combined sums (thread 0 of one workgroup).
-__device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float tag_scale, float fudge, float span_ticks,
-                            float* __restrict__ stats) {
+__device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float tag_scale, float fudge, float fd_eps,
+                            float span_ticks, float* __restrict__ stats) {
   const double s = (double)scale;
   double loss = 0.0, c1 = 0.0, c2 = 0.0;
+  // Pearlmutter finite differences (fd_eps > 0): first-order direction v = kd * data + kr * grad of the objective at
+  // scale 1, and the step eps_n = eps / |grad| (objectives.py:343-346, :468-486)
+  double kd = 0.0, kr = 0.0, rr_fd = 0.0;
   if (kind <= BH_GM_ANGULAR) {
     const double dot = v[0], rr = v[1], dd = v[2];
     const double rn = sqrt(rr), dn = sqrt(dd);
@@ -74,6 +81,9 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
     // d cos / d r = d * inv - r * dot / (rr * rn * dn)
     const double dcos_d = inv;
     const double dcos_r = -dot * inv / rr;
+    kd = -dcos_d;  // first_order_cosine = data / (-|g| |d|) + grad * <g,d> / (|g|^3 |d|)
+    kr = -dcos_r;
+    rr_fd = rr;
     if (kind == BH_GM_ANGULAR) {
       // objectives.py:210-214: acos(clamp(cos, -1+f, 1-f)) / pi * scale
       const double lo = -1.0 + (double)fudge, hi = 1.0 - (double)fudge;
@@ -89,9 +99,12 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
       c1 = -s * dcos_d;
       c2 = (kind == BH_GM_COSINE_FAST) ? 0.0 : -s * dcos_r;  // fast variant: norms detached (:268-269)
     }
-  } else if (kind == BH_GM_L2) {
-    loss = s * 0.5 * v[0];  // objectives.py:95
+  } else if (kind == BH_GM_L2 || kind == BH_GM_PEARL_L2) {
+    loss = s * 0.5 * v[0];  // objectives.py:95, :459
     c1 = s;
+    kd = -1.0;  // residuals = grad - data (:455)
+    kr = 1.0;
+    rr_fd = v[1];
   } else if (kind == BH_GM_L1) {
     loss = s * 0.5 * v[1];  // objectives.py:166
     c2 = 0.5 * s;
@@ -108,14 +121,19 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
   stats[BH_GM_STAT_S2] = (float)v[2];
   stats[BH_GM_STAT_SPAN_TICKS] = span_ticks;
   stats[7] = 0.f;
+  const double eps_n = fd_eps > 0.f ? (double)fd_eps / sqrt(rr_fd) : 0.0;
+  stats[BH_GM_STAT_PATCH_D] = (float)(eps_n * kd);
+  stats[BH_GM_STAT_PATCH_R] = (float)(eps_n * kr);
+  stats[BH_GM_STAT_FD_STEP] = (float)eps_n;
+  stats[BH_GM_STAT_FD_SCALE] = fd_eps > 0.f ? (float)(s / eps_n) : 0.f;
 }
 
 // Fixed-order combine of `n_rows` partial rows by ONE 256-thread workgroup, then the epilogue: thread t sums rows
 // t, t+256, ... (two for a single launch group at the default cap), wave64 shuffles, one LDS slot per wave, thread 0 finishes.  Each
 // row also carries the wall-clock stamps of its workgroup; their envelope is the span of the forward launch.
 __device__ void gm_combine_rows(int kind, const double* __restrict__ partials, int n_rows, float scale, float tag_scale,
-                                float fudge, float* __restrict__ stats, double* __restrict__ span_accum, double* lds,
-                                int* span_lds) {
+                                float fudge, float fd_eps, float* __restrict__ stats, double* __restrict__ span_accum,
+                                double* lds, int* span_lds) {
   double v[3] = {0.0, 0.0, 0.0};
   const bool want_span = span_accum != nullptr;  // bench-only bookkeeping: off the product path (two dependent loads less)
   const unsigned int base_tick =
@@ -167,7 +185,7 @@ __device__ void gm_combine_rows(int kind, const double* __restrict__ partials, i
     span_accum[0] += (double)span_ticks;
     span_accum[1] += 1.0;
   }
-  gm_epilogue(kind, v, scale, tag_scale, fudge, span_ticks, stats);
+  gm_epilogue(kind, v, scale, tag_scale, fudge, fd_eps, span_ticks, stats);
 }
 
 template <int KIND>
@@ -228,11 +246,11 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
 
 // Combine + epilogue (one workgroup).
 __global__ __launch_bounds__(kBlock) void gm_finalize_kernel(int kind, const double* __restrict__ partials, int n_rows,
-                                                             float scale, float tag_scale, float fudge,
+                                                             float scale, float tag_scale, float fudge, float fd_eps,
                                                              float* __restrict__ stats, double* __restrict__ span_accum) {
   __shared__ double lds[bh::kWavesPerBlock * 3];
   __shared__ int span_lds[bh::kWavesPerBlock * 2];
-  gm_combine_rows(kind, partials, n_rows, scale, tag_scale, fudge, stats, span_accum, lds, span_lds);
+  gm_combine_rows(kind, partials, n_rows, scale, tag_scale, fudge, fd_eps, stats, span_accum, lds, span_lds);
 }
 
 template <int KIND>
@@ -313,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void gm_pack_kernel(GmPtrs ptrs, int tensor
   }
 }
 
-bool valid_kind(int kind) { return kind >= BH_GM_COSINE && kind <= BH_GM_TAG; }
+bool valid_kind(int kind) { return kind >= BH_GM_COSINE && kind <= BH_GM_PEARL_L2; }
 
 // Fill the kernarg pointer block for launch group `g`; returns false on a misaligned / null pointer.
 bool fill_ptrs(GmPtrs& out, const void* const* ptrs, int n_tensors, int g) {
@@ -494,6 +512,9 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
       case BH_GM_L1:
         BH_FWD(BH_GM_L1);
         break;
+      case BH_GM_PEARL_L2:
+        BH_FWD(BH_GM_PEARL_L2);
+        break;
       default:
         BH_FWD(BH_GM_TAG);
         break;
@@ -507,12 +528,12 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
 }
 
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
-                   float* stats_dev, double* span_accum_dev, void* stream) {
+                   float fd_eps, float* stats_dev, double* span_accum_dev, void* stream) {
   if (!valid_kind(kind) || partials_dev == nullptr || n_rows <= 0 || n_rows > INT32_MAX || stats_dev == nullptr)
     return BH_EINVAL;
   if ((reinterpret_cast<uintptr_t>(partials_dev) & 31u) != 0) return BH_EINVAL;  // rows are read as 32-byte vectors
   hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), kind, partials_dev, (int)n_rows,
-                     scale, tag_scale, fudge, stats_dev, span_accum_dev);
+                     scale, tag_scale, fudge, fd_eps, stats_dev, span_accum_dev);
   return bh::launch_status();
 }
 
@@ -556,6 +577,7 @@ int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
                                         grad_flat, st, ev);
         break;
       case BH_GM_L2:
+      case BH_GM_PEARL_L2:  // same derivative as the euclidean objective
         launch_bwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st, ev);
         break;
       case BH_GM_L1:

@@ -56,9 +56,9 @@ __global__ __launch_bounds__(kBlock) void mt_kernel(MtPtrs ptrs, int tensor_base
   const float* __restrict__ b = ptrs.b[t];
   const float* __restrict__ c = c_flat ? c_flat + ch.flat_off : ptrs.c[t];
   float* __restrict__ o = out_flat + ch.flat_off;
-  if (coef) {
-    k0 = coef[0];
-    k1 = coef[1];
+  if (coef) {  // patch: the host value k0 is the multiplier of the device coefficient pair
+    k1 = k0 * coef[1];
+    k0 = k0 * coef[0];
   }
   const int tid = threadIdx.x;
   const int n4 = ch.len >> 2;
@@ -257,10 +257,10 @@ int bh_mt_scale(int32_t n_tensors, const void* const* a_ptrs, float alpha, const
 }
 
 int bh_mt_patch(int32_t n_tensors, const void* const* theta_ptrs, const void* const* grad_ptrs, const float* data_flat,
-                const float* coef_dev, const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-                float* out_flat, void* stream) {
+                const float* coef_dev, float mult, const bh_gm_chunk* chunks_dev, int64_t n_chunks,
+                const int32_t* group_chunk_begin, float* out_flat, void* stream) {
   if (grad_ptrs == nullptr || data_flat == nullptr || coef_dev == nullptr) return BH_EINVAL;
-  return run_mt<kPatch>(n_tensors, theta_ptrs, grad_ptrs, nullptr, data_flat, 0.f, 0.f, coef_dev, chunks_dev, n_chunks,
+  return run_mt<kPatch>(n_tensors, theta_ptrs, grad_ptrs, nullptr, data_flat, mult, 0.f, coef_dev, chunks_dev, n_chunks,
                         group_chunk_begin, out_flat, stream, false);
 }
 

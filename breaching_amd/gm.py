@@ -176,8 +176,9 @@ class GradientMatchPlan:
         return True
 
     # -- launches --------------------------------------------------------------------------------------------------
-    def forward(self, kind, rec, scale, tag_scale=0.0, fudge=1e-7, weights=None):
-        """Enqueue forward reduction + finalize; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS]."""
+    def forward(self, kind, rec, scale, tag_scale=0.0, fudge=1e-7, weights=None, fd_eps=0.0):
+        """Enqueue forward reduction + finalize; returns the fresh fp32 statistics record [BH_GM_STAT_WORDS].
+        ``fd_eps`` > 0 also fills the finite-difference words the Pearlmutter objectives read."""
         lib = _lib.load()
         stats = torch.empty(_lib.BH_GM_STAT_WORDS, dtype=torch.float32, device=self.device)
         # per-call workspace (16 KB): trials that run concurrently on different streams share this plan
@@ -194,7 +195,7 @@ class GradientMatchPlan:
         if ev0 is not None:
             _lib.check(lib.bh_event_record(ev0, stream), "bh_event_record")
         _lib.check(
-            lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_rows, float(scale), float(tag_scale), float(fudge),
+            lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_rows, float(scale), float(tag_scale), float(fudge), float(fd_eps),
                                _lib.ptr(stats), _lib.ptr(self.span_accum if self.span_enabled else None), stream),
             "bh_gm_finalize",
         )
@@ -218,6 +219,23 @@ class GradientMatchPlan:
 
     def split(self, grad_flat):
         return [grad_flat[o : o + n].view(s) for o, n, s in zip(self.flat_offsets, self.numels, self.shapes)]
+
+    def patched_parameters(self, params, grads, stats, mult):
+        """theta + mult * eps_n * v(grad, data) for the whole list in one launch (bh_mt_patch), v's coefficients read from
+        the statistics record on the device.  Returns T views of one packed buffer."""
+        lib = _lib.load()
+        if getattr(self, "_mt_bounds", None) is None:
+            self._mt_bounds = (c_int32 * (lib.bh_mt_num_groups(self.n_tensors) + 1))()
+            _lib.check(lib.bh_mt_group_bounds(self.n_tensors, self._chunks_host, self.n_chunks, self._mt_bounds), "bh_mt_group_bounds")
+        out = torch.empty(max(self.flat_elems, 4), dtype=torch.float32, device=self.device)
+        coef = c_void_p(stats.data_ptr() + _lib.GM_STAT_PATCH_D * 4)
+        _lib.check(
+            lib.bh_mt_patch(self.n_tensors, self._pointer_array(params), self._pointer_array(grads), _lib.ptr(self.data_flat), coef,
+                            float(mult), _lib.ptr(self.chunks_dev), self.n_chunks, self._mt_bounds, _lib.ptr(out),
+                            _lib.current_stream_handle(self.device)),
+            "bh_mt_patch",
+        )
+        return self.split(out)
 
 
 class ListLayout:
@@ -549,7 +567,108 @@ class HipEuclideanTag(HipGradientLoss):
         )
 
 
-# objectives.py:496-506.  The Pearlmutter finite-difference objectives are a SURVEY section 8(f) "next" row.
+class _AttachGradient(torch.autograd.Function):
+    """value with a prescribed derivative: d value / d candidate := `grad` (the finite-difference estimate)."""
+
+    @staticmethod
+    def forward(ctx, candidate, value, grad):
+        ctx.save_for_backward(grad)
+        return value.clone()
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (grad,) = ctx.saved_tensors
+        return grad * gout, None, None
+
+
+class HipPearlmutterEuclidean(HipGradientLoss):
+    """objectives.py:279-460 -- the double backward is replaced by a finite difference of first-order gradients: with
+    g = dL/dtheta, v = d objective / d g and eps_n = eps / |g|,
+        d objective / d x  ~  scale * ( dL/dx (theta + eps_n v) - dL/dx (theta) ) / eps_n        ("forward"; also "backward",
+    "central", "upwind").  The reference patches the live parameters in place and restores them afterwards; here the
+    offset parameters are written out of place (bh_mt_patch, coefficients and eps_n stay on the device) and the second pass
+    runs through `torch.func.functional_call`, so nothing needs restoring.  The estimate is attached to the objective value as
+    its derivative with respect to the candidate (the reference adds it to `candidate.grad` directly, :354-356)."""
+
+    kind_name = "pearlmutter-loss"
+
+    def __init__(self, scale=1.0, eps=1e-3, level_gradients=False, fudge_factor=1e-6, task_regularization=0.0,
+                 implementation="forward", **kwargs):
+        super().__init__(scale, task_regularization)
+        self.eps = eps
+        self.level_gradients = level_gradients
+        self.fudge_factor = fudge_factor
+        self.implementation = implementation
+
+    def initialize(self, loss_fn, cfg_impl, local_hyperparams=None):
+        if local_hyperparams is not None:  # :304-305
+            raise ValueError("This loss is only implemented for local gradients so far.")
+        if self.implementation not in ("forward", "backward", "central", "upwind"):  # :316-317
+            raise ValueError(f"Invalid finite difference implementation {self.implementation} given.")
+        super().initialize(loss_fn, cfg_impl, None)
+
+    def _offset_gradient(self, model, names, buffers, params, candidate, labels):
+        from torch.func import functional_call
+
+        loss = self.loss_fn(functional_call(model, ({**dict(zip(names, params)), **buffers},), (candidate,)), labels)
+        (grad,) = torch.autograd.grad(loss, (candidate,), create_graph=False)
+        return grad
+
+    def forward(self, model, gradient_data, candidate, labels):
+        model.zero_grad()
+        names = [n for n, _ in model.named_parameters()]
+        params = [p for _, p in model.named_parameters()]
+        buffers = dict(model.named_buffers())
+        task_loss = self.loss_fn(model(candidate), labels)
+        *gradients, dLdx = torch.autograd.grad(task_loss, (*params, candidate), create_graph=False)
+        if self.level_gradients:  # :336-339
+            grad_norm = torch.stack([g.pow(2).sum() for g in gradients]).sum().sqrt()
+            torch._foreach_div_(gradients, max(grad_norm, self.fudge_factor))
+        plan = self._plan_for(gradients, gradient_data)
+        if plan.n_tensors != len(gradients):
+            raise ValueError("Pearlmutter objectives need one observed gradient per model parameter.")  # foreach ops of :455
+        gradients = plan._prepare(gradients)
+        kind = _lib.GM_KINDS[self.kind_name]
+        with torch.cuda.device(plan.device):
+            stats = plan.forward(kind, gradients, float(self.scale), 0.0, 1e-7, None, fd_eps=float(self.eps))
+            theta = plan._prepare([p.detach() for p in params])
+            inv_step = stats[_lib.GM_STAT_FD_SCALE : _lib.GM_STAT_FD_SCALE + 1]  # scale / eps_n, on the device
+            if self.implementation == "forward":  # :347-354
+                shifted = self._offset_gradient(model, names, buffers, plan.patched_parameters(theta, gradients, stats, 1.0), candidate, labels)
+                estimate = (shifted - dLdx) * inv_step
+            elif self.implementation == "backward":  # :375-382
+                shifted = self._offset_gradient(model, names, buffers, plan.patched_parameters(theta, gradients, stats, -1.0), candidate, labels)
+                estimate = (dLdx - shifted) * inv_step
+            else:
+                plus = self._offset_gradient(model, names, buffers, plan.patched_parameters(theta, gradients, stats, 0.5), candidate, labels)
+                minus = self._offset_gradient(model, names, buffers, plan.patched_parameters(theta, gradients, stats, -0.5), candidate, labels)
+                if self.implementation == "central":  # :401-413
+                    estimate = (plus - minus) * inv_step
+                else:  # "upwind" :436-444 -- the reference takes torch.max / torch.min ALONG DIM 0 of dL/dx here; kept
+                    step = stats[_lib.GM_STAT_FD_STEP : _lib.GM_STAT_FD_STEP + 1]
+                    d_plus, d_minus = (plus - dLdx) / step, (dLdx - minus) / step
+                    estimate = (torch.max(dLdx, 0)[0] * d_minus + torch.min(dLdx, 0)[0] * d_plus) * self.scale
+        if self.task_regularization != 0:
+            estimate = estimate + self.task_regularization * dLdx  # :356
+        objective = _AttachGradient.apply(candidate, stats[0:1], estimate)
+        return objective, task_loss.detach()
+
+    def __repr__(self):
+        return (
+            f"Pearlmutter-type Finite Differences Loss with scale={self.scale} and task reg={self.task_regularization}."
+            f"Finite Difference Eps: {self.eps}. Level gradients: {self.level_gradients}. "
+            f"{f'Fudge-factor: {self.fudge_factor}' if self.level_gradients else ''} [HIP gfx950]"
+        )
+
+
+class HipPearlmutterCosine(HipPearlmutterEuclidean):
+    """objectives.py:463-493 -- the same finite difference along the first-order direction of the cosine objective."""
+
+    kind_name = "cosine-similarity"
+
+
+# objectives.py:496-506
 objective_lookup = {
     "euclidean": HipEuclidean,
     "cosine-similarity": HipCosineSimilarity,
@@ -558,4 +677,6 @@ objective_lookup = {
     "angular": HipAngularSimilarity,
     "l1": HipL1Loss,
     "tag-euclidean": HipEuclideanTag,
+    "pearlmutter-loss": HipPearlmutterEuclidean,
+    "pearlmutter-cosine": HipPearlmutterCosine,
 }

@@ -64,7 +64,8 @@ enum bh_gm_kind {
   BH_GM_ANGULAR = 3,       /* AngularSimilarity  acos(cos)/pi          objectives.py:210-214 */
   BH_GM_L2 = 4,            /* Euclidean._euclidean                     objectives.py:89-95   */
   BH_GM_L1 = 5,            /* L1Loss._l1loss                           objectives.py:158-166 */
-  BH_GM_TAG = 6            /* EuclideanTag._weighted_euclidean_l1      objectives.py:133-141 */
+  BH_GM_TAG = 6,           /* EuclideanTag._weighted_euclidean_l1      objectives.py:133-141 */
+  BH_GM_PEARL_L2 = 7       /* PearlmutterEuclidean residual: 0.5 sum (g-d)^2 plus |g|^2   objectives.py:451-460 */
 };
 
 /* Words of the statistics record written by bh_gm_finalize (fp32 each). */
@@ -76,7 +77,12 @@ enum bh_gm_stat {
   BH_GM_STAT_S1 = 4,
   BH_GM_STAT_S2 = 5,
   BH_GM_STAT_SPAN_TICKS = 6, /* wall-clock ticks between the first block entering and the last block leaving bh_gm_fwd */
-  BH_GM_STAT_WORDS = 8
+  /* Pearlmutter finite differences (fd_eps > 0, cosine kinds and BH_GM_PEARL_L2), objectives.py:343-356: */
+  BH_GM_STAT_PATCH_D = 8,   /* eps_n * coefficient of `data` in the first-order direction (read by bh_mt_patch) */
+  BH_GM_STAT_PATCH_R = 9,   /* eps_n * coefficient of `grad` */
+  BH_GM_STAT_FD_STEP = 10,  /* eps_n = fd_eps / |grad|_2 */
+  BH_GM_STAT_FD_SCALE = 11, /* scale / eps_n: multiplies (dL_offset/dx - dL/dx) */
+  BH_GM_STAT_WORDS = 12
 };
 
 /* Host-side helper: size the chunk table for a list of `n_tensors` tensors with `numel[i]` elements.
@@ -124,7 +130,8 @@ int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
  * reference: objectives.py:95 (0.5*objective), :141, :166, :195, :211-214, :243, :271 and the `* self.scale`
  * at :86, :126, :155, :178. */
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
-                   float* stats_dev, double* span_accum_dev, void* stream);
+                   float fd_eps, float* stats_dev, double* span_accum_dev, void* stream);
+/* `fd_eps` > 0 additionally fills the BH_GM_STAT_PATCH_* / FD_* words for the Pearlmutter objectives; 0 otherwise. */
 /* Every forward workgroup stamps the constant-rate device wall clock (bh_wall_clock_khz) on entry and exit into the
  * spare word of its partial row; when `span_accum_dev` is non-NULL the finalize kernel reduces them to the launch's
  * span (stats[BH_GM_STAT_SPAN_TICKS]) and adds it to span_accum_dev[0] and 1 to span_accum_dev[1] (doubles).  This is
@@ -246,13 +253,14 @@ int bh_mt_axpy(int32_t n_tensors, const void* const* a_ptrs, const void* const* 
 /* out = alpha * a; a NULL entry of a_ptrs reads as zeros.  The backward of bh_mt_axpy with respect to b. */
 int bh_mt_scale(int32_t n_tensors, const void* const* a_ptrs, float alpha, const bh_gm_chunk* chunks_dev, int64_t n_chunks,
                 const int32_t* group_chunk_begin, float* out_flat, void* stream);
-/* out = theta + (coef[0] * data + coef[1] * grad): the model parameters offset along the first-order direction of the
+/* out = theta + mult * (coef[0] * data + coef[1] * grad): the model parameters offset along the first-order direction of the
  * gradient-matching objective, coefficients read from the device (the finalize kernel writes them at
  * stats[BH_GM_STAT_PATCH_D .. BH_GM_STAT_PATCH_R], already multiplied by the finite-difference step).
  * reference: objectives.py:347-352 (`torch._foreach_add_(model.parameters(), first_order_grad, alpha=eps_n)`), :468-486. */
 int bh_mt_patch(int32_t n_tensors, const void* const* theta_ptrs, const void* const* grad_ptrs, const float* data_flat,
-                const float* coef_dev, const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-                float* out_flat, void* stream);
+                const float* coef_dev, float mult, const bh_gm_chunk* chunks_dev, int64_t n_chunks,
+                const int32_t* group_chunk_begin, float* out_flat, void* stream);
+/* `mult` scales both coefficients: +1 forward differences, -1 backward, +-0.5 central (objectives.py:347, :375, :401-406). */
 
 /* OrthogonalityRegularization on x[B, D] (D = C*H*W): value = sum over ordered pairs i != j of mean_k (x_ik * x_jk)^2
  * (the reference does not apply `scale`), analytic gradient into grad_out[B, D], per-workgroup partial values into
