@@ -72,7 +72,7 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
   double loss = 0.0, c1 = 0.0, c2 = 0.0;
   // Pearlmutter finite differences (fd_eps > 0): first-order direction v = kd * data + kr * grad of the objective at
   // scale 1, and the step eps_n = eps / |grad| (objectives.py:343-346, :468-486)
-  double kd = 0.0, kr = 0.0, rr_fd = 0.0;
+  double kd = 0.0, kr = 0.0;
   if (kind <= BH_GM_ANGULAR) {
     const double dot = v[0], rr = v[1], dd = v[2];
     const double rn = sqrt(rr), dn = sqrt(dd);
@@ -83,7 +83,6 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
     const double dcos_r = -dot * inv / rr;
     kd = -dcos_d;  // first_order_cosine = data / (-|g| |d|) + grad * <g,d> / (|g|^3 |d|)
     kr = -dcos_r;
-    rr_fd = rr;
     if (kind == BH_GM_ANGULAR) {
       // objectives.py:210-214: acos(clamp(cos, -1+f, 1-f)) / pi * scale
       const double lo = -1.0 + (double)fudge, hi = 1.0 - (double)fudge;
@@ -104,7 +103,6 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
     c1 = s;
     kd = -1.0;  // residuals = grad - data (:455)
     kr = 1.0;
-    rr_fd = v[1];
   } else if (kind == BH_GM_L1) {
     loss = s * 0.5 * v[1];  // objectives.py:166
     c2 = 0.5 * s;
@@ -121,7 +119,10 @@ __device__ void gm_epilogue(int kind, const double (&v)[3], float scale, float t
   stats[BH_GM_STAT_S2] = (float)v[2];
   stats[BH_GM_STAT_SPAN_TICKS] = span_ticks;
   stats[7] = 0.f;
-  const double eps_n = fd_eps > 0.f ? (double)fd_eps / sqrt(rr_fd) : 0.0;
+  // |grad|^2 is the second sum for every kind the finite differences apply to (cosine family, BH_GM_PEARL_L2).  Read it
+  // straight from v[1]: carrying it through the branch chain above as a third variable was miscompiled by hipcc 7.2 for
+  // kind == BH_GM_PEARL_L2 (the value arrived as 0, eps_n = inf; seen in the ISA and on the GPU).
+  const double eps_n = fd_eps > 0.f ? (double)fd_eps / sqrt(v[1]) : 0.0;
   stats[BH_GM_STAT_PATCH_D] = (float)(eps_n * kd);
   stats[BH_GM_STAT_PATCH_R] = (float)(eps_n * kr);
   stats[BH_GM_STAT_FD_STEP] = (float)eps_n;

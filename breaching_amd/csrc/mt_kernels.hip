@@ -31,10 +31,18 @@ enum MtOp { kAxpy = 0, kAxpyMinus = 1, kScale = 2, kPatch = 3 };
 // op(a, b, c) per element.  k0 / k1: alpha (axpy, scale) or the two direction coefficients (patch).
 template <int OP>
 __device__ __forceinline__ float mt_elem(float a, float b, float c, float k0, float k1) {
-  if constexpr (OP == kAxpy) return __fadd_rn(a, __fmul_rn(k0, b));                              // a + alpha*b
-  if constexpr (OP == kAxpyMinus) return __fsub_rn(__fadd_rn(a, __fmul_rn(k0, b)), c);          // (a + alpha*b) - c
-  if constexpr (OP == kScale) return __fmul_rn(k0, a);                                          // alpha*a
-  return a + (k0 * c + k1 * b);  // patch: theta + (k0 * data + k1 * grad); b = grad, c = packed data
+#pragma clang fp contract(off)  // torch rounds `lr * grad` and `param - (.)` separately: no fused multiply-add here
+  if constexpr (OP == kAxpy) {
+    const float t = k0 * b;
+    return a + t;  // a + alpha*b
+  }
+  if constexpr (OP == kAxpyMinus) {
+    const float t = k0 * b;
+    const float u = a + t;
+    return u - c;  // (a + alpha*b) - c
+  }
+  if constexpr (OP == kScale) return k0 * a;  // alpha*a
+  return a + (k0 * c + k1 * b);               // patch: theta + (k0 * data + k1 * grad); b = grad, c = packed data
 }
 
 template <int OP>

@@ -508,7 +508,8 @@ def test_pearlmutter_objectives_match_reference_on_a_smooth_model(name, plain, g
         (estimate,) = torch.autograd.grad(value, candidate)
         assert all(torch.equal(a, b) for a, b in zip(before, case.model.parameters()))  # the live parameters are never touched
         key = f"{name}_{implementation}"
-        assert value.item() == pytest.approx(float(gold[f"{key}__value"]), rel=LOSS_RTOL)
+        # the reference forms 1 - cos in fp32 (cos = 1 - 3e-5 here: 2e-3 relative rounding noise); ours sums in fp64
+        assert value.item() == pytest.approx(float(gold[f"{key}__value"]), rel=LOSS_RTOL, abs=2e-7)
         assert float(task_loss) == pytest.approx(float(gold[f"{key}__task_loss"]), rel=1e-5)
         got = estimate.cpu().numpy()
         ref = gold[f"{key}__grad"]
