@@ -219,8 +219,8 @@ def main():
                 if bytes_per is not None:
                     kernels[key].update(algorithmic_bytes=bytes_per, achieved_GBs=bytes_per / (avg_us * 1e-6) / 1e9)
         if "fin" in kernels:
-            kernels["fin"]["note"] = ("gm_finalize_kernel (one workgroup, <= 512 rows): hipEventRecord pair around the launch, "
-                                      "an upper bound of the dispatch duration rocprofv3 reports")
+            kernels["fin"]["note"] = ("gm_finalize_kernel (one workgroup, <= 512 rows): start/stop events of "
+                                      "hipExtLaunchKernelGGL, like the forward launch")
     # Kernel A forward: average launch duration from HIP events (hipExtLaunchKernelGGL start/stop events = the dispatch's
     # own begin/end timestamps, the quantity rocprofv3 reports).  A replayed graph cannot carry events, so when the timed
     # region ran as graph replays they come from the eager continuation right after it, and the device wall-clock span

@@ -92,7 +92,10 @@ _PROTOTYPES = {
     ),
     "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32)]),
     "bh_gm_set_rows_cap": (c_int32, [c_int32]),
-    "bh_gm_finalize": (c_int, [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "bh_gm_finalize": (
+        c_int,
+        [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "bh_wall_clock_khz": (c_int32, []),
     "bh_gm_bwd": (
         c_int,

@@ -197,8 +197,13 @@ class HipOptimizationAttacker:
             return None
         template = copy.deepcopy(self.model_template).to("cpu")
         loss_fn = copy.deepcopy(self.loss_fn).to("cpu") if isinstance(self.loss_fn, torch.nn.Module) else self.loss_fn
-        self._pool = workers.TrialWorkerPool(devices, workers.attacker_runner_factory,
-                                             (type(self).__name__, template, loss_fn, self.cfg))
+        try:
+            self._pool = workers.TrialWorkerPool(devices, workers.attacker_runner_factory,
+                                                 (type(self).__name__, template, loss_fn, self.cfg))
+        except Exception as exc:  # e.g. a victim model class the workers cannot import: all trials stay on this GPU
+            log.warning(f"Could not start the trial workers on devices {devices} ({exc!r}); running every trial on "
+                        f"{self.setup['device']}.")
+            self._pool = None
         return self._pool
 
     def close(self):

@@ -529,12 +529,17 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
 }
 
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
-                   float fd_eps, float* stats_dev, double* span_accum_dev, void* stream) {
+                   float fd_eps, float* stats_dev, double* span_accum_dev, void* stream, void* ev_start, void* ev_stop) {
   if (!valid_kind(kind) || partials_dev == nullptr || n_rows <= 0 || n_rows > INT32_MAX || stats_dev == nullptr)
     return BH_EINVAL;
   if ((reinterpret_cast<uintptr_t>(partials_dev) & 31u) != 0) return BH_EINVAL;  // rows are read as 32-byte vectors
-  hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), kind, partials_dev, (int)n_rows,
-                     scale, tag_scale, fudge, fd_eps, stats_dev, span_accum_dev);
+  if (ev_start || ev_stop)
+    hipExtLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream),
+                          static_cast<hipEvent_t>(ev_start), static_cast<hipEvent_t>(ev_stop), 0, kind, partials_dev,
+                          (int)n_rows, scale, tag_scale, fudge, fd_eps, stats_dev, span_accum_dev);
+  else
+    hipLaunchKernelGGL(gm_finalize_kernel, dim3(1), dim3(kBlock), 0, bh::as_stream(stream), kind, partials_dev, (int)n_rows,
+                       scale, tag_scale, fudge, fd_eps, stats_dev, span_accum_dev);
   return bh::launch_status();
 }
 

@@ -192,15 +192,11 @@ class GradientMatchPlan:
             "bh_gm_fwd",
         )
         ev0, ev1 = self._timed("fin")
-        if ev0 is not None:
-            _lib.check(lib.bh_event_record(ev0, stream), "bh_event_record")
         _lib.check(
             lib.bh_gm_finalize(kind, _lib.ptr(partials), self.n_rows, float(scale), float(tag_scale), float(fudge), float(fd_eps),
-                               _lib.ptr(stats), _lib.ptr(self.span_accum if self.span_enabled else None), stream),
+                               _lib.ptr(stats), _lib.ptr(self.span_accum if self.span_enabled else None), stream, ev0, ev1),
             "bh_gm_finalize",
         )
-        if ev1 is not None:
-            _lib.check(lib.bh_event_record(ev1, stream), "bh_event_record")
         return stats
 
     def backward(self, kind, rec, stats, gout, weights=None):

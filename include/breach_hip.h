@@ -130,7 +130,7 @@ int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
  * reference: objectives.py:95 (0.5*objective), :141, :166, :195, :211-214, :243, :271 and the `* self.scale`
  * at :86, :126, :155, :178. */
 int bh_gm_finalize(int32_t kind, const double* partials_dev, int64_t n_rows, float scale, float tag_scale, float fudge,
-                   float fd_eps, float* stats_dev, double* span_accum_dev, void* stream);
+                   float fd_eps, float* stats_dev, double* span_accum_dev, void* stream, void* ev_start, void* ev_stop);
 /* `fd_eps` > 0 additionally fills the BH_GM_STAT_PATCH_* / FD_* words for the Pearlmutter objectives; 0 otherwise. */
 /* Every forward workgroup stamps the constant-rate device wall clock (bh_wall_clock_khz) on entry and exit into the
  * spare word of its partial row; when `span_accum_dev` is non-NULL the finalize kernel reduces them to the launch's

@@ -11,7 +11,17 @@ from breaching_amd.cases import build_case, build_text_case, initial_candidate, 
 parser = argparse.ArgumentParser()
 parser.add_argument("--full", action="store_true")
 parser.add_argument("--only", default=None)
+parser.add_argument("--same-process", action="store_true", help="run all configurations inside this process")
 args = parser.parse_args()
+if args.only is None and not args.same_process:
+    # One process per configuration, the way attacks are run in practice.  (Observed in round 2: inside ONE process the 4-in-flight
+    # restarts of configs[3], started after the ResNet-50 / DeepInversion run of configs[2], did not finish within a 12-minute
+    # limit, while the same configuration alone takes 207 s -- cause not yet understood, see DESIGN.md open items.)
+    import subprocess
+
+    for k in "12345":
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--only", k] + (["--full"] if args.full else []))
+    raise SystemExit(0)
 dev = torch.device("cuda:0")
 setup = dict(device=dev, dtype=torch.float)
 out = {}
