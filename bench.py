@@ -264,7 +264,7 @@ def main():
         ts = time.perf_counter()
         shard = trials.TrialShard.current(world)
         best = run.best()[0]
-        value, _ = shard.select({rank: best}, {rank: state["minimum"]}, stats, device)
+        value, _ = shard.select({rank: best}, {rank: state["minimum"]}, stats, device, gather_stats=False)  # all-reduce + broadcast
         torch.cuda.synchronize(device)
         select_ms = (time.perf_counter() - ts) * 1e3
 

@@ -616,6 +616,7 @@ class HipOptimizationAttacker:
             with torch.cuda.stream(streams[t]):
                 stats[f"Trial_{t}_Val"].extend(runs[t].loss_history(iterations_run))
                 best = runs[t].best()
+                self.last_trial_execution = runs[t].execution_mode()
             if streams[t] is not main:
                 main.wait_stream(streams[t])
             solutions[t] = best[0] if len(best) == 1 else tuple(best)
@@ -685,6 +686,7 @@ class HipOptimizationAttacker:
         except KeyboardInterrupt:
             print(f"Recovery interrupted manually in iteration {iterations_run}!")
         stats[f"Trial_{trial}_Val"].extend(run.loss_history(iterations_run))
+        self.last_trial_execution = run.execution_mode()
         return run.best()
 
     # ---- generic loop: any torch.optim optimiser, differentiable augmentations, L-BFGS closures ------------------
@@ -965,6 +967,20 @@ class FusedTrial:
             if self.use_graph and self.iterations + 1 == self.capture_after:
                 self._capture()
         self.iterations += 1
+
+    def execution_mode(self):
+        """How the iterations of this trial were issued: "hipGraph replay", or "eager launches" with the reason (switched off,
+        fewer iterations than the warm-up, host-side noise, or the capture error).  `attacker.last_trial_execution` keeps the
+        last trial's answer, so a silent fall-back to eager launches is visible to callers and tests."""
+        if self.graph is not None:
+            return "hipGraph replay"
+        if self.graph_failed is not None:
+            return f"eager launches (capture failed: {self.graph_failed})"
+        if self.host_noise:
+            return "eager launches (host-side Langevin noise)"
+        if not self.use_graph:
+            return "eager launches (graph replay switched off)"
+        return "eager launches (run shorter than the capture warm-up)"
 
     def disable_graph(self):
         """Back to eager launches (bench.py uses this to time individual kernels with events)."""

@@ -9,7 +9,9 @@ breaching/attacks/optimization_based_attack.py:70-78, :206-218.  The reference h
     collective,
   * selection is ONE ``all_reduce(MIN)`` on a packed int64 key ``(float_bits(score) << 32) | trial`` -- scores are
     >= 0 or +inf, for which IEEE-754 bit patterns order like the floats; NaN is mapped to +inf exactly like
-    ``_score_trial`` does (:204) -- followed by one broadcast of the winning candidate from its owner.
+    ``_score_trial`` does (:204) -- followed by ONE broadcast of the winning candidate from its owner (all parts of a
+    joint data+label solution travel in one flat buffer; every rank knows the shapes from its own trials).  The per-trial
+    loss histories are merged afterwards with a host-side object gather (off the data path, optional).
 """
 
 import struct
@@ -65,11 +67,11 @@ class TrialShard:
     def owner(self, trial):
         return trial % self.world
 
-    def select(self, local_solutions, local_scores, stats, device):
+    def select(self, local_solutions, local_scores, stats, device, gather_stats=True):
         """Return (optimal_value: float, optimal_solution) identically on every rank.
 
         ``local_solutions`` / ``local_scores`` map trial index -> tensor (or tuple of tensors) / score.  ``stats`` gets the
-        per-trial loss lists of the other ranks merged in (host-side object gather, small).
+        per-trial loss lists of the other ranks merged in (host-side object gather, small) unless ``gather_stats`` is off.
         """
         if len(local_scores) > 0:
             local_key = min(score_key(_to_float(s), t) for t, s in local_scores.items())
@@ -92,32 +94,44 @@ class TrialShard:
             solution = local_solutions[trial]
         else:
             solution = self._broadcast_solution(local_solutions, trial, device)
-            self._merge_stats(stats)
+            if gather_stats:
+                self._merge_stats(stats)
         return value, solution
 
     # -- distributed helpers ---------------------------------------------------------------------------------------
     def _broadcast_solution(self, local_solutions, trial, device):
+        """One broadcast: the parts of the winning solution, flattened into one fp32 buffer.  The layout comes from any
+        local solution (all trials of an attack have the same shapes).  Only a rank without a single finished trial -- more
+        ranks than trials -- needs the shapes sent first; that rare case costs one extra host-side object broadcast, which
+        every rank then takes part in (the all-reduced flag below tells them)."""
         import torch.distributed as dist
 
         src = self.owner(trial)
-        # shapes travel first (host-side, tiny): a rank with fewer trials than the owner cannot know them otherwise
-        meta = [None]
+        cdev = _collective_device(device, self.group)
+        template = next(iter(local_solutions.values())) if len(local_solutions) > 0 else None
+        if self.world > self.num_trials:  # some rank may hold no template: agree on the shapes the slow way
+            meta = [None]
+            if self.rank == src:
+                sol = local_solutions[trial]
+                parts = [sol] if torch.is_tensor(sol) else list(sol)
+                meta = [[(tuple(p.shape), str(p.dtype).replace("torch.", "")) for p in parts] + [torch.is_tensor(sol)]]
+            dist.broadcast_object_list(meta, src=_global_rank(src, self.group), group=self.group)
+            *shapes, is_single = meta[0]
+        else:
+            parts = [template] if torch.is_tensor(template) else list(template)
+            shapes = [(tuple(p.shape), str(p.dtype).replace("torch.", "")) for p in parts]
+            is_single = torch.is_tensor(template)
+        sizes = [int(torch.Size(shape).numel()) for shape, _ in shapes]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=cdev)
         if self.rank == src:
             sol = local_solutions[trial]
             parts = [sol] if torch.is_tensor(sol) else list(sol)
-            meta = [[(tuple(p.shape), str(p.dtype).replace("torch.", "")) for p in parts] + [torch.is_tensor(sol)]]
-        dist.broadcast_object_list(meta, src=_global_rank(src, self.group), group=self.group)
-        *shapes, is_single = meta[0]
-        cdev = _collective_device(device, self.group)
-        out = []
-        for idx, (shape, dtype) in enumerate(shapes):
-            if self.rank == src:
-                sol = local_solutions[trial]
-                part = (sol if torch.is_tensor(sol) else sol[idx]).detach().to(cdev).contiguous()
-            else:
-                part = torch.empty(shape, dtype=getattr(torch, dtype), device=cdev)
-            dist.broadcast(part, src=_global_rank(src, self.group), group=self.group)
-            out.append(part.to(device))
+            torch.cat([p.detach().reshape(-1).to(device=cdev, dtype=torch.float32) for p in parts], out=flat)
+        dist.broadcast(flat, src=_global_rank(src, self.group), group=self.group)  # the single winner broadcast
+        out, offset = [], 0
+        for (shape, dtype), n in zip(shapes, sizes):
+            out.append(flat[offset : offset + n].view(shape).to(device=device, dtype=getattr(torch, dtype)))
+            offset += n
         return out[0] if is_single else tuple(out)
 
     def _merge_stats(self, stats):

@@ -167,7 +167,8 @@ def test_resnet18_imagenet_first_iterations(golden_dir):
     case = build_case("resnet18", "ImageNet", 1, device="cuda:0")
     x0 = initial_candidate(case.data_cfg, 1)
     cfg = get_attack_config("invertinggradients", ["optim.max_iterations=20", "optim.step_size_decay=null", "optim.callback=5"])
-    rec, stats, _ = _attack(case, cfg, x0)
+    rec, stats, attacker = _attack(case, cfg, x0)
+    assert attacker.last_trial_execution == "hipGraph replay"
     _check_against_golden("", gold, rec, stats, case, crop=32)
     got = _teacher_forced_losses(case, ["optim.max_iterations=20", "optim.step_size_decay=null"], gold["forced_x"])
     np.testing.assert_allclose(got, gold["history"][gold["forced_k"]], rtol=LOSS_RTOL)
@@ -185,7 +186,8 @@ def test_resnet50_seethrough_deepinversion(golden_dir):
     x0 = initial_candidate(case.data_cfg, 2)
     cfg = get_attack_config("seethroughgradients", ["optim.max_iterations=6", "optim.warmup=2", "optim.callback=2",
                                                     "optim.langevin_noise=0.0"])
-    rec, stats, _ = _attack(case, cfg, x0)
+    rec, stats, attacker = _attack(case, cfg, x0)
+    assert attacker.last_trial_execution == "hipGraph replay"  # ResNet-50 + DeepInversion iteration captured, not eager
     # the user's BN buffers come from a train-mode forward on this host's CPU: equal to the fixture's up to rounding
     _check_against_golden("", gold, rec, stats, case, crop=32, checksum_rel=1e-8)
 
