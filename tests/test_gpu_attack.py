@@ -9,7 +9,9 @@ point moved by 16 ulp, leaves its own trajectory after a handful of iterations (
 other hardware, can stay within 1e-4 of one particular trajectory for long.  The tests therefore assert
   (1) 1e-4 on the loss at the reference's OWN iterates (teacher forcing: our objective + priors evaluated at x_k taken
       from the reference run, early and late in the optimisation),
-  (2) 1e-4 on the free-running loss trajectory for as long as the reference's twin runs themselves agree to 3e-5,
+  (2) 1e-4 on the free-running loss trajectory for as long as the reference's twin runs themselves agree to 1e-5 (a
+      tenth of the tolerance: our own GPU runs differ from each other as well -- MIOpen's backward kernels use atomics -- and
+      an iteration where the twins are 2.6e-5 apart was seen to put two of our runs 2.5e-4 apart),
   (3) afterwards, agreement within a band derived from the reference's own twin runs (10x their deviation, floor 3e-4
       right after the fork, 2 % once a twin has left by 1e-3),
   (4) PSNR within 0.1 dB (or the twin spread if that is larger).
@@ -40,7 +42,7 @@ def _attack(case, cfg, x0, dryrun=False, seed=7):
     return rec, stats, attacker
 
 
-def _reproducible_horizon(hist_ref, twins, tol=3e-5):
+def _reproducible_horizon(hist_ref, twins, tol=1e-5):
     """First iteration at which any twin run of the reference deviates from the reference by more than `tol`."""
     if twins is None:
         return len(hist_ref)
