@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- attack iterations/sec of the MI355X hot path, with roofline and CPU-baseline legs.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W        (N > 1: launched through torch.distributed.run)
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1: the driver launches it through torch.distributed.run (one rank per GPU); a bare `python bench.py --gpus N` re-launches
+  itself the same way.  With fewer GPUs than ranks (a 1-GPU box) the ranks share devices and agree over gloo -- a functional
+  check only, flagged "oversubscribed": true.
 
   * workload = BASELINE.json configs[1]: ResNet-18 (1000 classes, random init), ImageNet-shaped 1x3x224x224 candidate,
     attack=invertinggradients (cosine-similarity gradient matching + TV 0.2, hard-sign Adam lr 0.1, box projection,
@@ -11,7 +14,9 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W        (N > 1:
   * N GPUs = N independent restarts (trials), one per rank (weak scaling); value = N*K / max-over-ranks wall time.
     After the timed region the ranks agree on the best trial with ONE all-reduce(MIN) + one broadcast (RCCL).
   * roofline: the fused gradient-matching reduction (kernel A forward, gm_fwd_kernel): algorithmic bytes 2*N*4 per launch
-    over the average launch duration measured with HIP events on the launch stream inside the timed region.
+    over the average launch duration measured with HIP events (hipExtLaunchKernelGGL start/stop = the dispatch's own
+    timestamps) on the launch stream; `stage_*` adds the one-workgroup finalize launch; `timed_region_span_*` is the device
+    wall-clock span of the forward launches inside the timed graph-replay region.
   * cpu_baseline: oracle/restate.py (CPU restatement of the reference, pinned to it by tests/test_oracle_pinning.py) on
     the host cores, same workload, a bounded number of iterations, rank 0 at N=1 only.
 """

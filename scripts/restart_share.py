@@ -1,3 +1,6 @@
+"""One GPU's share of BASELINE configs[3] through the public API with per-1000-iteration log lines: ResNet-18, four restarts in
+flight, N iterations each (default 3000).  `python scripts/restart_share.py 24000` is the full-length share; its
+"Trial 0" lines are profiles/r2_config4_share_steady_state.log (flat 1000 iterations / 8.45 s x 4 trials)."""
 import sys, os, time, logging, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
