@@ -364,6 +364,7 @@ class HipFeatureRegularization(torch.nn.Module):
         for measured in self.measured_features:
             objective = HipEuclidean(scale=2.0 * self.scale / max(measured.numel(), 1))
             objective.initialize(None, _NoMixedPrecision, None)
+            objective._plan_for_count(1, [measured])  # packed here, on the caller's stream, before any trial forks or captures
             self._objectives.append(objective)
 
     def release_graph(self):

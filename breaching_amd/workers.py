@@ -192,9 +192,10 @@ class TrialWorkerPool:
             except Exception:
                 pass
         if dist.is_initialized():
+            # Also when forced: a default process group left behind would make the next attacker of this process believe it
+            # is one rank of a (dead) group.  Tearing the group down is a local operation.
             try:
-                if not force:
-                    dist.destroy_process_group()
+                dist.destroy_process_group()
             except Exception:
                 pass
         for proc, conn in self.workers:

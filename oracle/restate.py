@@ -116,6 +116,95 @@ def gradient_objective(kind, rec, data, cfg_objective=None):
     raise ValueError(f"Unknown objective type {kind} given.")
 
 
+def multi_step_update(model, loss_fn, candidate, hyperparams):
+    """objectives.py:48-72 (FedAvg unroll): `steps` local SGD steps on consecutive slices of the candidate batch, the shared
+    quantity is p_local - p_server.  Plain list comprehensions, like the reference."""
+    from torch.func import functional_call
+
+    names = [n for n, _ in model.named_parameters()]
+    server = [p for _, p in model.named_parameters()]
+    buffers = dict(model.named_buffers())
+    params = server
+    seen, task_loss = 0, None
+    for i in range(hyperparams["steps"]):
+        data = candidate[seen : seen + hyperparams["data_per_step"]]
+        seen = (seen + hyperparams["data_per_step"]) % candidate.shape[0]
+        task_loss = loss_fn(functional_call(model, ({**dict(zip(names, params)), **buffers},), (data,)), hyperparams["labels"][i])
+        grads = torch.autograd.grad(task_loss, params, create_graph=True)
+        params = [p - hyperparams["lr"] * g for p, g in zip(params, grads)]
+    return [p_local - p_server for p_local, p_server in zip(params, server)], task_loss
+
+
+def pearlmutter_estimate(model, loss_fn, gradient_data, candidate, labels, kind="pearlmutter-loss", scale=1.0, eps=1e-3,
+                         task_regularization=0.0, implementation="forward"):
+    """objectives.py:279-493: objective value, task loss and the finite-difference estimate the reference ADDS to
+    candidate.grad.  Out of place (the reference patches the live parameters and restores them, :326-328): with g = dL/dtheta,
+    v = d objective / d g (residual :455, or the first-order cosine direction :468-477) and eps_n = eps / |g| (:346),
+        forward  (:347-354)  scale * (dL/dx(theta + eps_n v) - dL/dx(theta)) / eps_n
+        backward (:375-382)  scale * (dL/dx(theta) - dL/dx(theta - eps_n v)) / eps_n
+        central  (:401-413)  scale * (dL/dx(theta + eps_n v / 2) - dL/dx(theta - eps_n v / 2)) / eps_n
+        upwind   (:436-444)  scale * (max_0(dL/dx) * D_minus + min_0(dL/dx) * D_plus), max / min taken ALONG DIM 0
+    plus task_regularization * dL/dx (:356)."""
+    from torch.func import functional_call
+
+    names = [n for n, _ in model.named_parameters()]
+    params = [p for _, p in model.named_parameters()]
+    buffers = dict(model.named_buffers())
+    x = candidate.detach().clone().requires_grad_(True)
+    task_loss = loss_fn(model(x), labels)
+    *grads, dLdx = torch.autograd.grad(task_loss, (*params, x))
+    if kind == "pearlmutter-loss":
+        direction = [g - d for g, d in zip(grads, gradient_data)]
+        value = 0.5 * scale * torch.stack([r.pow(2).sum() for r in direction]).sum()
+    elif kind == "pearlmutter-cosine":
+        dot = sum((g * d).sum() for g, d in zip(grads, gradient_data))
+        gn = torch.stack([g.pow(2).sum() for g in grads]).sum().sqrt()
+        dn = torch.stack([d.pow(2).sum() for d in gradient_data]).sum().sqrt()
+        direction = [d / (-gn * dn) + g * (dot / (gn.pow(3) * dn)) for g, d in zip(grads, gradient_data)]
+        value = scale * (1 - dot / (gn * dn))
+    else:
+        raise ValueError(kind)
+    eps_n = eps / torch.stack([g.pow(2).sum() for g in grads]).sum().sqrt()
+
+    def gradient_at(moved):
+        xs = candidate.detach().clone().requires_grad_(True)
+        loss = loss_fn(functional_call(model, ({**dict(zip(names, moved)), **buffers},), (xs,)), labels)
+        return torch.autograd.grad(loss, xs)[0]
+
+    def offset(base, mult):  # torch._foreach_add_(params, direction, alpha=mult * eps_n), out of place
+        return [torch.add(p.detach(), v, alpha=float(mult * eps_n)) for p, v in zip(base, direction)]
+
+    def central_pair():
+        # the reference moves the live parameters by +eps_n/2 and then by -eps_n from THERE (:401-408), so the second point
+        # carries the rounding of the first
+        at_plus = offset(params, 0.5)
+        return gradient_at(at_plus), gradient_at(offset(at_plus, -1.0))
+
+    if implementation == "forward":
+        estimate = (gradient_at(offset(params, 1.0)) - dLdx) / eps_n * scale
+    elif implementation == "backward":
+        estimate = (dLdx - gradient_at(offset(params, -1.0))) / eps_n * scale
+    elif implementation == "central":
+        plus, minus = central_pair()
+        estimate = (plus - minus) / eps_n * scale
+    elif implementation == "upwind":
+        plus, minus = central_pair()
+        d_plus, d_minus = (plus - dLdx) / eps_n, (dLdx - minus) / eps_n
+        estimate = (torch.max(dLdx, 0)[0] * d_minus + torch.min(dLdx, 0)[0] * d_plus) * scale
+    else:
+        raise ValueError(implementation)
+    return value.detach(), task_loss.detach(), estimate + task_regularization * dLdx
+
+
+def orthogonality_penalty(x):
+    """regularizers.py:170-178 (the value is not multiplied by `scale` there)."""
+    if x.shape[0] == 1:
+        return x.new_zeros(())
+    B = x.shape[0]
+    products = (x.unsqueeze(0) * x.unsqueeze(1)).pow(2).view(B, B, -1).mean(dim=2)
+    return products.sum() - products.diagonal().sum()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # priors  (breaching/attacks/auxiliaries/regularizers.py)
 # ---------------------------------------------------------------------------------------------------------------

@@ -130,6 +130,61 @@ def test_c_oracle_candidate_step_against_torch_adam(kernels_oracle):
         np.testing.assert_allclose(p.detach().numpy(), x, rtol=1e-5, atol=1e-6)
 
 
+def test_restated_pearlmutter_objectives_match_reference_golden(golden_dir):
+    """oracle/restate.py::pearlmutter_estimate (out of place, functional_call) against the unmodified reference's in-place
+    implementation (run through the legacy-torch shim, oracle/make_golden.py::golden_pearlmutter) on the kink-free model."""
+    from breaching_amd.cases import build_case, initial_candidate, parameter_checksum
+    from oracle import restate
+
+    gold = _gold(golden_dir, "pearlmutter.npz")
+    case = build_case("smoothnet", "CIFAR10", 2)
+    assert parameter_checksum(case.model) == pytest.approx(float(gold["smooth_model_checksum"]), rel=1e-12)
+    x0 = initial_candidate(case.data_cfg, 2, seed=int(gold["x0_seed"]))
+    labels = case.shared_data[0]["metadata"]["labels"]
+    for name in ("pearlmutter-loss", "pearlmutter-cosine"):
+        for implementation in ("forward", "backward", "central", "upwind"):
+            value, task_loss, estimate = restate.pearlmutter_estimate(
+                case.model, case.loss_fn, case.shared_data[0]["gradients"], x0, labels, kind=name, scale=0.7, eps=1e-3,
+                task_regularization=0.05, implementation=implementation)
+            key = f"{name}_{implementation}"
+            assert float(value) == pytest.approx(float(gold[f"{key}__value"]), rel=1e-5, abs=1e-9)
+            assert float(task_loss) == pytest.approx(float(gold[f"{key}__task_loss"]), rel=1e-6)
+            want = gold[f"{key}__grad"]
+            err = float(np.abs(estimate.numpy() - want).max()) / float(np.abs(want).max())
+            # same CPU, same BLAS, the same sequence of parameter offsets: the estimates coincide (any difference in the offset
+            # arithmetic would be amplified by 1 / eps_n into percents of the peak -- that is the fp32 finite-difference noise
+            # which keeps the reference's own estimate 1 % (euclidean) / 6 % (cosine) away from the exact gradient)
+            print(f"  {key}: {err:.3e} of peak")
+            assert err <= 1e-5, (key, err)
+
+
+def test_restated_orthogonality_and_fedavg_unroll_match_reference(golden_dir):
+    from breaching_amd.cases import build_fedavg_case, initial_candidate
+    from oracle import restate
+
+    gold = _gold(golden_dir, "kernels.npz")
+    x = torch.tensor(gold["orth_x"], requires_grad=True)
+    value = restate.orthogonality_penalty(x)
+    (g,) = torch.autograd.grad(value, x)
+    assert float(value) == pytest.approx(float(gold["orth__value"][0]), rel=2e-6)
+    assert float(np.abs(g.numpy() - gold["orth__grad"]).max()) <= 2e-6 * _peak([gold["orth__grad"]])
+    from oracle.ref_shim import have_reference, import_reference
+
+    if have_reference():
+        import_reference()
+        from breaching.attacks.auxiliaries.objectives import Euclidean
+
+        case = build_fedavg_case()
+        x0 = initial_candidate(case.data_cfg, 4, seed=6).requires_grad_(True)
+        hp = case.shared_data[0]["metadata"]["local_hyperparams"]
+        ref = Euclidean()
+        ref.initialize(case.loss_fn, type("Impl", (), dict(mixed_precision=False))(), hp)
+        want, _ = ref._grad_fn_multi_step(case.model, x0, None)
+        got, _ = restate.multi_step_update(case.model, case.loss_fn, x0, hp)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
 # ---- loop-level restatement --------------------------------------------------------------------------------------
 def _cpu_case(model, data, n, **kw):
     from breaching_amd.cases import build_case
