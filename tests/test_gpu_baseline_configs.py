@@ -86,7 +86,8 @@ def test_resnet18_1000_iterations_end_of_run_matches_the_reference_distribution(
     after each milestone -- must be statistically indistinguishable from the reference's own eight runs:
       * means agree within 4 standard errors (Welch), and for PSNR also within north_star's 0.1 dB,
       * every HIP run lies within the reference's range widened by 3 reference standard deviations,
-      * the run-to-run spread is of the same size (variance ratio within [1/9, 9])."""
+      * the run-to-run spread is of the same size (variance ratio within [1/16, 16]: with 7 + 7 degrees of freedom a ratio
+        beyond that has p < 0.002 when the distributions are equal; measured 0.4 - 2.0)."""
     from breaching_amd import get_attack_config
     from breaching_amd.cases import initial_candidate, psnr, ulp_perturb
 
@@ -126,7 +127,7 @@ def test_resnet18_1000_iterations_end_of_run_matches_the_reference_distribution(
             failures.append(f"{name}: means differ by {abs(mh - mr) / se:.1f} standard errors")
         if h.min() < r.min() - 3 * sr or h.max() > r.max() + 3 * sr:
             failures.append(f"{name}: a run lies outside the reference range widened by 3 sigma")
-        if not (1 / 9 <= (sh ** 2) / (sr ** 2) <= 9):
+        if not (1 / 16 <= (sh ** 2) / (sr ** 2) <= 16):
             failures.append(f"{name}: run-to-run variance ratio {(sh / sr) ** 2:.2f}")
     if abs(np.mean(hip["psnr"]) - ref["psnr"].mean()) > PSNR_TOL_DB:
         failures.append("psnr: mean differs by more than 0.1 dB")
