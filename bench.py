@@ -36,10 +36,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def pmc_traffic_bytes(kernel):
-    """HBM bytes per launch from the committed PMC passes (profiles/r*_pmc_{fetch,write}_pmc_summary.csv):
-    FETCH_SIZE (KB) x 2 -- the gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md section HBM -- plus
-    WRITE_SIZE (KB).  bench.py cannot collect counters itself; None when the profiles are absent."""
+def pmc_traffic_bytes(kernel, sources=None):
+    """HBM bytes per launch from the committed PMC passes (profiles/r*_pmc_{fetch,write}_pmc_summary.csv, the newest of
+    each): FETCH_SIZE (KB) x 2 -- the gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md section HBM -- plus
+    WRITE_SIZE (KB).  bench.py cannot collect counters itself (separate rocprofv3 --pmc passes do, scripts/gpu_profile.sh);
+    None when the profiles are absent.  `sources` (a list) receives the file names used."""
     import csv
     import glob
 
@@ -54,6 +55,8 @@ def pmc_traffic_bytes(kernel):
                 if row["kernel"].startswith(kernel):
                     total += float(row["avg_value"]) * 1024.0 * factor
                     found += 1
+                    if sources is not None:
+                        sources.append(os.path.basename(paths[-1]))
                     break
     return int(total) if found == 2 else None
 
@@ -231,10 +234,13 @@ def main():
     # region ran as graph replays they come from the eager continuation right after it, and the device wall-clock span
     # (first workgroup in -> last workgroup out) of every launch INSIDE the timed region is reported next to them.
     fwd_bytes = 2 * n_elements * 4
+    traffic_files = []
     if "fwd" in kernels:
         k = kernels["fwd"]
         roofline = dict(bound="hbm", kernel="gm_fwd_kernel<cosine>", achieved=round(k["achieved_GBs"], 1), peak=HBM_PEAK_GBS,
-                        unit="GB/s", frac=round(k["achieved_GBs"] / HBM_PEAK_GBS, 4), traffic=pmc_traffic_bytes("gm_fwd_kernel"),
+                        unit="GB/s", frac=round(k["achieved_GBs"] / HBM_PEAK_GBS, 4),
+                        traffic=pmc_traffic_bytes("gm_fwd_kernel", traffic_files),
+                        traffic_source="committed rocprofv3 --pmc passes (not collected in this run): " + ", ".join(traffic_files),
                         avg_launch_us=round(k["avg_us"], 2), launches=k["launches"], algorithmic_bytes=fwd_bytes,
                         measured="HIP start/stop events of hipExtLaunchKernelGGL on the launch stream, " +
                                  ("inside the timed region" if timed_with_events else
