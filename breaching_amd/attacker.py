@@ -115,6 +115,7 @@ class HipOptimizationAttacker:
         preset = getattr(self, "_preset", None)  # a trial worker: starting points and labels come from rank 0
         pool = self._trial_worker_pool(num_trials) if preset is None else None
         if pool is not None:  # host copies of the caller's inputs, taken before prepare_attack rebinds / normalises them
+            "ClassAttack" in server_secrets  # noqa: B015 -- None raises TypeError here, in the caller, as in the reference (:82)
             job_inputs = dict(server_payload=workers.to_cpu(list(server_payload)), shared_data=workers.to_cpu(list(shared_data)),
                               server_secrets=workers.to_cpu(server_secrets), initial_data=workers.to_cpu(initial_data), dryrun=dryrun)
         rec_models, labels, stats = self.prepare_attack(server_payload, shared_data)
