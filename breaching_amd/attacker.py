@@ -121,7 +121,12 @@ class HipOptimizationAttacker:
         rec_models, labels, stats = self.prepare_attack(server_payload, shared_data)
         if preset is not None and preset["labels"] is not None:
             labels = preset["labels"].to(self.setup["device"])
-        shard = trials.TrialShard.current(num_trials)
+        if pool is None and preset is None and workers.active_pool() is not None:
+            # The default process group belongs to an idle worker pool (a one-trial call on this attacker, or another
+            # attacker's pool): nobody would join a collective, so this call is a single rank.
+            shard = trials.TrialShard(num_trials)
+        else:
+            shard = trials.TrialShard.current(num_trials)
         num_points = shared_data[0]["metadata"]["num_data_points"]
         # Device RNG order.  The reference draws trial t's starting point right before trial t runs, and its Langevin
         # noise draws (:169) sit between consecutive starting points.  Without noise the order of the starting-point draws
@@ -192,7 +197,7 @@ class HipOptimizationAttacker:
         if pool is not None and not pool.closed:
             return pool
         if dist.is_available() and dist.is_initialized():
-            return None
+            return None  # pre-launched ranks (torch.distributed.run), or another attacker's pool owns the group
         devices = workers.requested_devices(self.cfg, self.setup["device"])[:num_trials]
         if len(devices) < 2:
             return None

@@ -29,6 +29,17 @@ import torch
 log = logging.getLogger(__name__)
 
 
+_ACTIVE_POOL = None
+
+
+def active_pool():
+    """The worker pool that owns this process's default process group, or None.  While a pool is idle (no job submitted),
+    `torch.distributed.is_initialized()` is true although nobody else will join a collective -- callers that did not submit
+    work to the pool must not shard over that group."""
+    pool = _ACTIVE_POOL
+    return pool if pool is not None and not getattr(pool, "closed", True) else None
+
+
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
@@ -142,6 +153,8 @@ class TrialWorkerPool:
             self.close(force=True)
             raise
         self.closed = False
+        global _ACTIVE_POOL
+        _ACTIVE_POOL = self
         log.info(f"Trial worker pool up: {self.world} ranks on devices {self.devices} ({backend}).")
 
     # -- messaging -------------------------------------------------------------------------------------------------
@@ -183,9 +196,12 @@ class TrialWorkerPool:
     def close(self, force=False):
         import torch.distributed as dist
 
+        global _ACTIVE_POOL
         if getattr(self, "closed", False):
             return
         self.closed = True
+        if _ACTIVE_POOL is self:
+            _ACTIVE_POOL = None
         for proc, conn in self.workers:
             try:
                 conn.send(("stop",))

@@ -30,10 +30,13 @@ def test_pool_runs_jobs_selects_and_survives_errors():
     from breaching_amd import trials
     from breaching_amd.workers import TrialWorkerPool
 
+    from breaching_amd import workers
+
     num_trials = 5
+    assert workers.active_pool() is None
     pool = TrialWorkerPool([None, None, None], _runner_factory, (num_trials,))
     try:
-        assert pool.backend == "gloo" and pool.world == 3
+        assert pool.backend == "gloo" and pool.world == 3 and workers.active_pool() is pool
         for scores in ([3.0, 0.25, 7.0, float("nan"), 0.5], [9.0, 8.0, 7.0, 6.0, 0.125]):
             pool.submit([dict(scores=scores)] * 2)
             shard = trials.TrialShard.current(num_trials)
@@ -56,8 +59,7 @@ def test_pool_runs_jobs_selects_and_survives_errors():
         pool.close(force=True)
     import torch.distributed as dist
 
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    assert workers.active_pool() is None and not dist.is_initialized()  # the group never outlives its pool
 
 
 def test_requested_devices_parsing(monkeypatch):
