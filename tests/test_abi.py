@@ -205,3 +205,54 @@ def test_no_compatibility_layers_in_the_product():
                     if needle == "hipify" and f == "build.py":
                         continue  # mentioned in a comment explaining why torch's extension builder is not used
                     assert needle not in text, (f, needle)
+
+
+def test_forward_rows_and_mt_group_bounds_host_arithmetic(hip_lib):
+    """Persistent-grid sizing of kernel A (bh_gm_fwd_rows / bh_gm_set_rows_cap) and the 128-tensor launch groups of the
+    multi-tensor kernels (bh_mt_group_bounds): pure host arithmetic."""
+    from ctypes import byref, c_int32, c_int64
+
+    from breaching_amd import _lib
+
+    def table(numel):
+        arr = (c_int64 * len(numel))(*numel)
+        n_chunks, flat = c_int64(), c_int64()
+        assert hip_lib.bh_gm_table_size(len(numel), arr, byref(n_chunks), byref(flat)) == 0
+        chunks = (_lib.GmChunk * n_chunks.value)()
+        offs = (c_int64 * len(numel))()
+        assert hip_lib.bh_gm_build_table(len(numel), arr, chunks, n_chunks.value, offs) == 0
+        return chunks, n_chunks.value
+
+    try:
+        # ResNet-18 sized: 2893 chunks in one launch group -> ceil(2893 / ceil(2893 / cap)) workgroups
+        numel = [4096] * 2893
+        chunks, n = table(numel)
+        bounds = (c_int32 * (hip_lib.bh_gm_num_groups(len(numel)) + 1))()
+        assert hip_lib.bh_gm_group_bounds(len(numel), chunks, n, bounds) == 0
+        groups = hip_lib.bh_gm_num_groups(len(numel))
+        assert groups == 7 and bounds[groups] == n
+        for cap in (512, 2048, 100, 1):
+            assert hip_lib.bh_gm_set_rows_cap(cap) == 0
+            rows = hip_lib.bh_gm_fwd_rows(len(numel), bounds)
+            want = 0
+            for g in range(groups):
+                c = bounds[g + 1] - bounds[g]
+                rounds = -(-c // cap)
+                want += -(-c // rounds)
+                assert -(-c // rounds) <= cap
+            assert rows == want
+        assert hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS) == 0
+        one = (c_int32 * 2)(0, 2893)  # a single launch group holding all chunks (62 tensors in reality)
+        assert hip_lib.bh_gm_fwd_rows(62, one) == 483  # 6 rounds of 483 workgroups: every workgroup streams 5 or 6 chunks
+        assert hip_lib.bh_gm_fwd_rows(0, one) == -1 and hip_lib.bh_gm_fwd_rows(62, None) == -1
+    finally:
+        hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
+    # multi-tensor launch groups: 300 small tensors -> 3 groups of 128 / 128 / 44 tensors, one chunk each
+    numel = [10 + i for i in range(300)]
+    chunks, n = table(numel)
+    assert hip_lib.bh_mt_num_groups(300) == 3 and hip_lib.bh_mt_num_groups(0) == 0 and hip_lib.bh_mt_num_groups(128) == 1
+    bounds = (c_int32 * 4)()
+    assert hip_lib.bh_mt_group_bounds(300, chunks, n, bounds) == 0
+    assert list(bounds) == [0, 128, 256, 300]
+    assert all(chunks[i].tensor == i for i in range(n))
+    assert hip_lib.bh_mt_group_bounds(300, chunks, n, None) == -1
