@@ -12,6 +12,7 @@ import torch
 
 import breaching_amd
 from breaching_amd.cases import ResNet, psnr
+from breaching_amd.priors import psnr_on_device
 
 
 def main():
@@ -39,7 +40,9 @@ def main():
     reconstruction, stats = attacker.reconstruct(server_payload, shared_data, {}, dryrun=False)
 
     print(f"final objective {stats['Trial_0_Val'][-1]:.4f}, selected score {stats['opt_value']:.4f}, "
-          f"PSNR {psnr(reconstruction['data'], x_true, data_cfg):.2f} dB")
+          f"PSNR {psnr(reconstruction['data'], x_true, data_cfg):.2f} dB "
+          f"(on the device: {psnr_on_device(reconstruction['data'], x_true, data_cfg.mean, data_cfg.std)[0].item():.2f} dB)")
+    attacker.close()  # stops the per-GPU trial workers, if restarts were sharded over several GPUs
 
 
 if __name__ == "__main__":
