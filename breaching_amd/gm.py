@@ -7,8 +7,11 @@ reference: breaching/attacks/auxiliaries/objectives.py
     :169-196, ``AngularSimilarity`` :199-217, ``MaskedCosineSimilarity`` :220-244, ``FastCosineSimilarity`` :247-276
   * ``objective_lookup`` :496-506
 
-The victim model's forward / backward / double backward stay on PyTorch-ROCm; only the reduction over the
-per-parameter gradient list and its derivative run here.
+  * the FedAvg unroll ``_grad_fn_multi_step`` :48-72 and the Pearlmutter finite-difference objectives :279-493
+
+The victim model's forward / backward / double backward stay on PyTorch-ROCm; the reduction over the per-parameter
+gradient list and its derivative (kernel A), the parameter-list updates of the FedAvg local steps and the offset
+parameters of the Pearlmutter objectives (multi-tensor kernels, csrc/mt_kernels.hip) run here.
 """
 
 import ctypes

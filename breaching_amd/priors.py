@@ -1,9 +1,11 @@
 """Image priors on the HIP kernels (kernels C and D), behind the reference's regulariser interface.
 
 reference: breaching/attacks/auxiliaries/regularizers.py
-  * ``TotalVariation`` :103-153, ``NormRegularization`` :184-200, ``DeepInversion`` :203-230
+  * ``TotalVariation`` :103-153, ``NormRegularization`` :184-200, ``DeepInversion`` :203-230 (all BatchNorm inputs of
+    the model in three launches), ``FeatureRegularization`` :23-60, ``OrthogonalityRegularization`` :156-181
   * ``regularizer_lookup`` :233-239; every regulariser has ``initialize(models, shared_data, labels)`` and
     ``forward(tensor) -> scalar``.
+  * ``psnr_on_device``: breaching/analysis/metrics.py:108-130 on the GPU.
 The DeepInversion feature statistic is restated from its mathematical definition (the reference hook lives in an
 NVIDIA-NC licensed file, auxiliaries/deepinversion.py:84-107, and was not copied).
 """

@@ -1,6 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz by running the UNMODIFIED reference in the build container.
 
-    python -m oracle.make_golden [--only kernels|schedules|convnet|resnet18|seethrough]
+    python -m oracle.make_golden [--only configs|kernels|schedules|convnet|resnet18|seethrough|tag|variants|fedavg|labels|dlg|pearlmutter]
+    python -m oracle.make_golden --only resnet18_long|seethrough_b8|tag_bert_base      (slow: run by name only)
 
 Needs /root/reference (through oracle/ref_shim.py); the outputs are committed so that the GPU box -- which has no
 reference checkout -- can pin oracle/restate.py, oracle/kernels_oracle.c and the HIP path against real reference
