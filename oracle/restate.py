@@ -367,12 +367,30 @@ def run_attack(model, loss_fn, cfg, server_payload, shared_data, initial_data=No
     if "deep_inversion" in regs and regs["deep_inversion"]["scale"] > 0:
         di = DeepInversionPrior(**regs["deep_inversion"])
 
+    local_hyperparams = shared_data[0]["metadata"].get("local_hyperparams")
+
     def objective_and_task(candidate, kind, cfg_obj):
         total, task_total = 0, 0
         for m, dg in zip(models, data_grads):
             m.zero_grad()
-            task = loss_fn(m(candidate), labels)
-            grads = torch.autograd.grad(task, tuple(m.parameters()), create_graph=True)
+            if kind.startswith("pearlmutter"):
+                # objectives.py:322-329: the objective itself ADDS its finite-difference estimate to candidate.grad and returns
+                # a value without graph; only used inside the closure (scoring uses the plain objectives)
+                if local_hyperparams is not None:
+                    raise ValueError("This loss is only implemented for local gradients so far.")  # :304-305
+                value, task, estimate = pearlmutter_estimate(
+                    m, loss_fn, dg, candidate, labels, kind=kind, scale=cfg_obj.get("scale", 1.0), eps=cfg_obj.get("eps", 1e-3),
+                    task_regularization=cfg_obj.get("task_regularization", 0.0), implementation=cfg_obj.get("implementation", "forward"))
+                with torch.no_grad():
+                    candidate.grad += estimate
+                total = total + value
+                task_total = task_total + task
+                continue
+            if local_hyperparams is not None:  # FedAvg user: objectives.py:48-72
+                grads, task = multi_step_update(m, loss_fn, candidate, local_hyperparams)
+            else:
+                task = loss_fn(m(candidate), labels)
+                grads = torch.autograd.grad(task, tuple(m.parameters()), create_graph=True)
             obj = gradient_objective(kind, grads, dg, cfg_obj)
             if cfg_obj is not None and cfg_obj.get("task_regularization", 0.0) != 0:
                 obj = obj + cfg_obj["task_regularization"] * task
@@ -402,7 +420,7 @@ def run_attack(model, loss_fn, cfg, server_payload, shared_data, initial_data=No
         t0 = time.time()
         for iteration in range(n_iter):
             def closure():
-                optimizer.zero_grad()
+                optimizer.zero_grad(set_to_none=False)  # the reference's torch 1.10 zeroed the gradient (needed by :354)
                 total, task = objective_and_task(candidate, cfg.objective.type, cfg.objective)
                 for key in regs.keys():
                     r = regs[key]
@@ -416,7 +434,8 @@ def run_attack(model, loss_fn, cfg, server_payload, shared_data, initial_data=No
                         total = total + di(candidate)
                     else:
                         raise NotImplementedError(key)
-                total.backward(inputs=candidate)
+                if torch.is_tensor(total) and total.requires_grad:  # optimization_based_attack.py:164-165
+                    total.backward(inputs=candidate)
                 with torch.no_grad():
                     if optim.langevin_noise > 0:
                         candidate.grad += optim.langevin_noise * optimizer.param_groups[0]["lr"] * torch.randn_like(candidate.grad)

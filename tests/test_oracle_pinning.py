@@ -295,3 +295,42 @@ def test_attack_configs_match_reference_yaml(golden_dir):
         got = get_data_config(name)
         for key, value in want.items():
             assert list(got[key]) == list(value) if isinstance(value, list) else got[key] == value, (name, key)
+
+
+def _within_twin_band(stats, gold, prefix):
+    """Kink-sensitive trajectories (two chained local steps through max-pool / ReLU; finite differences): strict for as long as
+    the reference's own twins (starts <= 16 ulp apart) agree to 1e-5, then within 10x their running deviation."""
+    hist, ref, twins = np.asarray(stats["Trial_0_Val"]), gold[f"{prefix}history"], gold[f"{prefix}twin_history"]
+    assert len(hist) == len(ref)
+    dev = np.maximum.accumulate(np.abs(twins - ref[None, :]).max(axis=0))
+    forked = np.nonzero(dev / np.abs(ref) > 1e-5)[0]
+    horizon = int(forked[0]) if len(forked) else len(ref)
+    assert horizon >= 1
+    np.testing.assert_allclose(hist[:horizon], ref[:horizon], rtol=1e-5)
+    assert (np.abs(hist - ref)[horizon:] <= 10.0 * dev[horizon:]).all(), (np.abs(hist - ref) / np.maximum(dev, 1e-30)).max()
+    twin_opt = np.abs(gold[f"{prefix}twin_opt_value"] - float(gold[f"{prefix}opt_value"])).max()
+    assert abs(stats["opt_value"] - float(gold[f"{prefix}opt_value"])) <= max(10.0 * twin_opt, 1e-5 * float(gold[f"{prefix}opt_value"]))
+
+
+def test_restatement_fedavg_and_pearlmutter_attacks_match_reference_golden(golden_dir):
+    """The loop-level restatement on the FedAvg unroll (objectives.py:48-72) and on the Pearlmutter objectives (:279-493):
+    whole loss histories against the unmodified reference's runs."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case, build_fedavg_case, initial_candidate
+
+    gold = _gold(golden_dir, "attack_fedavg.npz")
+    case = build_fedavg_case()
+    x0 = initial_candidate(case.data_cfg, 4, seed=6)
+    cfg = get_attack_config("invertinggradients", ["optim.max_iterations=30", "optim.callback=10", "optim.signed=null",
+                                                   "optim.step_size=0.01"])
+    rec, stats = _run_restatement(case, cfg, x0)
+    _within_twin_band(stats, gold, "plain_")
+
+    gold = _gold(golden_dir, "pearlmutter.npz")
+    case = build_case("convnet", "CIFAR10", 2)
+    x0 = initial_candidate(case.data_cfg, 2, seed=int(gold["x0_seed"]))
+    for name, scoring in (("pearlmutter-loss", "euclidean"), ("pearlmutter-cosine", "cosine-similarity")):
+        cfg = get_attack_config("invertinggradients", [f"objective.type={name}", "optim.signed=soft", "optim.max_iterations=12",
+                                                       "optim.callback=6", f"restarts.scoring={scoring}"])
+        rec, stats = _run_restatement(case, cfg, x0)
+        _within_twin_band(stats, gold, name.replace("-", "_") + "_")
