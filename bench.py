@@ -77,6 +77,9 @@ def parse_args():
     p.add_argument("--roofline-steps", type=int, default=40, help="eager iterations with per-launch HIP events")
     p.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find mode)")
     p.add_argument("--channels-last", action="store_true", help="victim model and candidate in NHWC memory format")
+    p.add_argument("--no-dry-collective", action="store_true",
+                   help="N = 1 only: skip the one-rank RCCL run of the selection collectives (python -m breaching_amd.trials "
+                        "--dry-collective, a bounded subprocess after the timed region)")
     p.add_argument("--trials-per-gpu", type=int, default=1,
                    help="independent restarts in flight per GPU on separate streams (BASELINE configs[3]: 32 trials on 8 GPUs = 4)")
     return p.parse_args()
@@ -120,11 +123,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
+        import datetime
+
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        limit = datetime.timedelta(seconds=float(os.environ.get("BREACH_HIP_COLLECTIVE_TIMEOUT", "600")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=limit)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
 
@@ -268,23 +275,42 @@ def main():
         kernels["bwd"]["frac_of_hbm_peak"] = round(kernels["bwd"]["achieved_GBs"] / HBM_PEAK_GBS, 4)
 
     # ---- trial selection: the one collective of the multi-GPU path --------------------------------------------------
-    select_ms = None
+    select_ms = score_ms = None
     state = run.read_state()
     if world > 1:
         torch.cuda.synchronize(device)
         ts = time.perf_counter()
         shard = trials.TrialShard.current(world)
         best = run.best()[0]
-        value, _ = shard.select({rank: best}, {rank: state["minimum"]}, stats, device, gather_stats=False)  # all-reduce + broadcast
+        # scored exactly as `reconstruct` scores a finished trial (optimization_based_attack.py:191-204), not by the running minimum
+        score = attacker._score_trial(best, labels, rec_models, case.shared_data)
         torch.cuda.synchronize(device)
-        select_ms = (time.perf_counter() - ts) * 1e3
+        tm = time.perf_counter()
+        value, _ = shard.select({rank: best}, {rank: score}, stats, device, gather_stats=False)  # all-reduce + broadcast
+        torch.cuda.synchronize(device)
+        score_ms, select_ms = (tm - ts) * 1e3, (time.perf_counter() - tm) * 1e3
+
+    # ---- N = 1: the selection collectives through a one-rank RCCL communicator (bounded subprocess, off the timed region) ---
+    rccl_dry_run = None
+    if world == 1 and not args.no_dry_collective:
+        import subprocess
+
+        try:
+            proc = subprocess.run([sys.executable, "-m", "breaching_amd.trials", "--dry-collective", "nccl", str(device)], cwd=ROOT,
+                                  capture_output=True, text=True, timeout=150)
+            last = proc.stdout.strip().splitlines()[-1] if proc.stdout.strip() else ""
+            rccl_dry_run = json.loads(last) if proc.returncode == 0 and last.startswith("{") else dict(
+                ok=False, returncode=proc.returncode, stderr=proc.stderr[-400:])
+        except Exception as exc:  # a timeout included: reported, never fatal for the measurement
+            rccl_dry_run = dict(ok=False, error=repr(exc))
 
     # ---- CPU baseline (rank 0, N == 1 only) ---------------------------------------------------------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
         from oracle import restate
 
-        threads = min(os.cpu_count() or 1, 32)
+        host_cores = os.cpu_count() or 1
+        threads = min(host_cores, 32)  # torch's CPU convolutions stop scaling well before 32 threads on this workload
         torch.set_num_threads(threads)
         cpu_case = build_case(args.model, "ImageNet", 1, device="cpu")
         cpu_cfg = breaching_amd.get_attack_config("invertinggradients")
@@ -295,7 +321,7 @@ def main():
         restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
                            initial_data=x0_cpu, max_iterations=args.cpu_baseline_iters, timing=timing)
         cpu_baseline = dict(value=round(args.cpu_baseline_iters / timing[0], 3), unit="attack iterations/s", cores=threads,
-                            kind="port", sample=f"{args.cpu_baseline_iters} iterations of the same ResNet-18/224 invertinggradients "
+                            host_cpu_count=host_cores, kind="port", sample=f"{args.cpu_baseline_iters} iterations of the same ResNet-18/224 invertinggradients "
                             f"workload through oracle/restate.py (torch {torch.__version__} CPU), after 2 warm-up iterations")
 
     if rank == 0:
@@ -324,6 +350,8 @@ def main():
             "graph_capture_error": graph_failed,
             "final_objective": state["total"],
             "select_ms": select_ms,
+            "score_ms": score_ms,
+            "rccl_dry_run": rccl_dry_run,
             "collective_backend": backend if world > 1 else None,
             "oversubscribed": bool(oversubscribed),
         }

@@ -147,30 +147,47 @@ class HipOptimizationAttacker:
         local_scores, local_solutions = {}, {}
         mine = list(shard.local_trials())
         width = trials_in_flight(self.cfg) if (self._fused_loop_supported() and not noisy) else 1
+        self._trial_execution = {}
         try:
-            for start in range(0, len(mine), max(width, 1)):
-                group = mine[start : start + max(width, 1)]
-                if len(group) == 1:
-                    solutions = {group[0]: self._run_trial(rec_models, shared_data, labels, stats, group[0], initial_data,
-                                                           dryrun, init_state=inits.get(group[0]))}
-                else:
-                    solutions = self._run_trial_group(rec_models, shared_data, labels, stats, group, initial_data, dryrun,
-                                                      {t: inits[t] for t in group})
-                for trial, solution in solutions.items():
-                    local_solutions[trial] = solution
-                    local_scores[trial] = self._score_trial(self._solution_data(solution),
-                                                            self._score_labels(solution, labels), rec_models, shared_data)
-        except KeyboardInterrupt:
-            print("Trial procedure manually interruped.")
-        if pool is not None:
-            pool.expect("trials_done")  # a crashed worker raises here instead of hanging the selection collective
-            pool.broadcast(("go",))
-        before_select = getattr(self, "_before_select", None)
-        if before_select is not None:
-            before_select()
-        optimal = self._select_optimal_reconstruction(local_solutions, local_scores, stats, shard)
-        if pool is not None:
-            pool.expect("ok")
+            try:
+                for start in range(0, len(mine), max(width, 1)):
+                    group = mine[start : start + max(width, 1)]
+                    if len(group) == 1:
+                        solutions = {group[0]: self._run_trial(rec_models, shared_data, labels, stats, group[0], initial_data,
+                                                               dryrun, init_state=inits.get(group[0]))}
+                    else:
+                        solutions = self._run_trial_group(rec_models, shared_data, labels, stats, group, initial_data, dryrun,
+                                                          {t: inits[t] for t in group})
+                    for trial, solution in solutions.items():
+                        local_solutions[trial] = solution
+                        local_scores[trial] = self._score_trial(self._solution_data(solution),
+                                                                self._score_labels(solution, labels), rec_models, shared_data)
+            except KeyboardInterrupt:
+                print("Trial procedure manually interruped.")
+            if pool is not None:
+                pool.expect("trials_done")  # a crashed worker raises here instead of hanging the selection collective
+                pool.broadcast(("go",))
+            before_select = getattr(self, "_before_select", None)
+            if before_select is not None:
+                before_select()
+            stats["execution_trials"] = dict(self._trial_execution)  # merged over the ranks with the loss histories
+            optimal = self._select_optimal_reconstruction(local_solutions, local_scores, stats, shard)
+            if pool is not None:
+                pool.finish()
+        except BaseException:
+            # A failure on any rank between `submit` and the last `ok` -- a worker's error report, or this rank's own trials
+            # raising -- must not leave healthy workers waiting for a `go` that never comes (the next call would read their
+            # stale messages and enter the collective alone): cancel the job everywhere; a pool that cannot be drained is
+            # closed, and the next call starts a new one.
+            if pool is not None:
+                pool.abort()
+                if pool.closed:
+                    self._pool = None
+            raise
+        # How this call was executed, on the channel callers already read (base_attack.py:45): per-trial launch mode of
+        # this rank's trials, the pool that shared the trials (backend, world, devices) or why there was none.
+        stats["execution"] = dict(trials=stats.pop("execution_trials"), pool=pool.describe() if pool is not None else None,
+                                  pool_fallback=getattr(self, "_pool_fallback", None), world=shard.world)
         reconstructed_data = self._package(optimal, labels)
         if server_payload[0]["metadata"].modality == "text":
             raw = reconstructed_data["data"]
@@ -196,19 +213,29 @@ class HipOptimizationAttacker:
         pool = getattr(self, "_pool", None)
         if pool is not None and not pool.closed:
             return pool
-        if dist.is_available() and dist.is_initialized():
-            return None  # pre-launched ranks (torch.distributed.run), or another attacker's pool owns the group
+        self._pool_fallback = None
         devices = workers.requested_devices(self.cfg, self.setup["device"])[:num_trials]
         if len(devices) < 2:
             return None
+        foreign = workers.active_pool()
+        if foreign is not None and not foreign.busy:
+            # Another attacker of this process left its pool idle (it was not closed or collected yet): its workers hold
+            # that attacker's model.  Take the process group over instead of silently running on one GPU.
+            log.info("Closing another attacker's idle trial worker pool.")
+            foreign.close()
+        if dist.is_available() and dist.is_initialized():
+            return None  # pre-launched ranks (torch.distributed.run), or a busy pool of another attacker owns the group
         template = copy.deepcopy(self.model_template).to("cpu")
         loss_fn = copy.deepcopy(self.loss_fn).to("cpu") if isinstance(self.loss_fn, torch.nn.Module) else self.loss_fn
         try:
             self._pool = workers.TrialWorkerPool(devices, workers.attacker_runner_factory,
                                                  (type(self).__name__, template, loss_fn, self.cfg))
-        except Exception as exc:  # e.g. a victim model class the workers cannot import: all trials stay on this GPU
-            log.warning(f"Could not start the trial workers on devices {devices} ({exc!r}); running every trial on "
-                        f"{self.setup['device']}.")
+        except Exception as exc:  # e.g. a victim model class the workers cannot import
+            if _cfg_get(self.cfg.impl, "trial_pool", "auto") == "required":
+                raise
+            # all trials stay on this GPU; callers see it in stats["execution"]["pool_fallback"]
+            self._pool_fallback = f"could not start the trial workers on devices {devices}: {exc!r}"
+            log.warning(f"{self._pool_fallback}; running every trial on {self.setup['device']}.")
             self._pool = None
         return self._pool
 
@@ -218,6 +245,12 @@ class HipOptimizationAttacker:
         if pool is not None:
             pool.close()
             self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _adopt_initial_state(self, state):
         out = []
@@ -582,7 +615,9 @@ class HipOptimizationAttacker:
         main = torch.cuda.current_stream(device)
         # The first trial stays on the caller's stream: HIP multiplexes streams onto 4 hardware queues and the caller's
         # stream already holds one, so 1 + 3 side streams is the layout that gives every trial in flight its own queue.
-        streams = {t: (main if i == 0 else torch.cuda.Stream(device)) for i, t in enumerate(group)}
+        import os
+        keep_main = os.environ.get("BREACH_HIP_GROUP_MAIN_STREAM", "1") != "0"
+        streams = {t: (main if (i == 0 and keep_main) else torch.cuda.Stream(device)) for i, t in enumerate(group)}
         runs = {}
         for t in group:
             candidates = list(init_states[t])
@@ -623,10 +658,16 @@ class HipOptimizationAttacker:
                 stats[f"Trial_{t}_Val"].extend(runs[t].loss_history(iterations_run))
                 best = runs[t].best()
                 self.last_trial_execution = runs[t].execution_mode()
+                self._record_execution(t, self.last_trial_execution)
             if streams[t] is not main:
                 main.wait_stream(streams[t])
             solutions[t] = best[0] if len(best) == 1 else tuple(best)
         return solutions
+
+    def _record_execution(self, trial, mode):
+        record = getattr(self, "_trial_execution", None)
+        if record is not None:
+            record[trial] = mode
 
     # hooks the joint attacker overrides -------------------------------------------------------------------------
     def _labels_for_objective(self, candidates, labels):
@@ -693,6 +734,7 @@ class HipOptimizationAttacker:
             print(f"Recovery interrupted manually in iteration {iterations_run}!")
         stats[f"Trial_{trial}_Val"].extend(run.loss_history(iterations_run))
         self.last_trial_execution = run.execution_mode()
+        self._record_execution(trial, self.last_trial_execution)
         return run.best()
 
     # ---- generic loop: any torch.optim optimiser, differentiable augmentations, L-BFGS closures ------------------
@@ -733,6 +775,8 @@ class HipOptimizationAttacker:
                     break
         except KeyboardInterrupt:
             print(f"Recovery interrupted manually in iteration {iteration}!")
+        self.last_trial_execution = f"torch.optim loop ({optim.optimizer})"
+        self._record_execution(trial, self.last_trial_execution)
         return [b.detach() for b in best]
 
     def _compute_objective(self, candidates, labels, rec_model, optimizer, shared_data, iteration):
@@ -876,12 +920,26 @@ def trials_in_flight(cfg):
 
 def graph_replay_enabled(cfg):
     """hipGraph replay is on unless BREACH_HIP_GRAPH=0 or cfg.impl.hip_graph is false."""
+    return graph_replay_policy(cfg) != "off"
+
+
+def graph_replay_policy(cfg):
+    """"on" (default: a failed capture raises -- eager launches are 2.4x slower and nobody asked for them), "auto"
+    (a failed capture logs a warning and the trial continues with eager launches; `stats["execution"]` says so), or "off".
+    Set by cfg.impl.hip_graph (True / "auto" / False) or BREACH_HIP_GRAPH (1 / auto / 0)."""
     import os
 
-    if os.environ.get("BREACH_HIP_GRAPH", "1") == "0":
-        return False
-    flag = _cfg_get(cfg.impl, "hip_graph", True)
-    return bool(flag) if flag is not None else True
+    flag = os.environ.get("BREACH_HIP_GRAPH")
+    if flag is None:
+        flag = _cfg_get(cfg.impl, "hip_graph", True)
+    if flag is None:
+        return "on"
+    if isinstance(flag, str):
+        flag = flag.strip().lower()
+        if flag == "auto":
+            return "auto"
+        return "off" if flag in ("0", "false", "off", "no") else "on"
+    return "on" if bool(flag) else "off"
 
 
 class FusedTrial:
@@ -962,7 +1020,8 @@ class FusedTrial:
         self.graph = None
         self.graph_failed = None
         self.capture_after = GRAPH_WARMUP_ITERATIONS
-        self.use_graph = graph_replay_enabled(cfg) and not self.host_noise
+        self.graph_policy = graph_replay_policy(cfg)
+        self.use_graph = self.graph_policy != "off" and not self.host_noise
 
     def step(self):
         """One attack iteration: a graph replay when captured, the eager body otherwise."""
@@ -1009,10 +1068,16 @@ class FusedTrial:
             with torch.cuda.device(device), torch.cuda.graph(graph):
                 self._enqueue_iteration()
             self.graph = graph
-        except Exception as exc:  # stay on the eager HIP path; never leave the GPU
+        except Exception as exc:
             self.graph, self.use_graph, self.graph_failed = None, False, repr(exc)
-            log.warning(f"hipGraph capture of the attack iteration failed ({exc!r}); continuing with eager launches.")
             torch.cuda.synchronize(device)
+            if self.graph_policy != "auto":
+                raise RuntimeError(
+                    f"hipGraph capture of the attack iteration failed ({exc!r}). Set cfg.impl.hip_graph='auto' (or "
+                    "BREACH_HIP_GRAPH=auto) to continue with eager launches instead, or False to never capture."
+                ) from exc
+            # "auto": stay on the eager HIP path; never leave the GPU
+            log.warning(f"hipGraph capture of the attack iteration failed ({exc!r}); continuing with eager launches.")
 
     def _enqueue_iteration(self):
         lib, att, device = self.lib, self.attacker, self.device

@@ -49,8 +49,11 @@ def unpack_key(key):
 class TrialShard:
     """Which trials this process runs, and how the best one is agreed on."""
 
-    def __init__(self, num_trials, rank=0, world=1, group=None):
+    def __init__(self, num_trials, rank=0, world=1, group=None, always_collective=False):
         self.num_trials, self.rank, self.world, self.group = int(num_trials), int(rank), int(world), group
+        # world 1 normally never touches torch.distributed; `always_collective` sends even a one-rank selection through the
+        # all-reduce and the broadcast (how the RCCL code path is exercised on a 1-GPU box, see `dry_collective`)
+        self.always_collective = bool(always_collective)
 
     @classmethod
     def current(cls, num_trials, group=None):
@@ -77,39 +80,44 @@ class TrialShard:
             local_key = min(score_key(_to_float(s), t) for t, s in local_scores.items())
         else:
             local_key = score_key(float("inf"), 0xFFFFFFFF)
-        if self.world == 1:
+        collective = self.world > 1 or self.always_collective
+        if not collective:
             best_key = local_key
         else:
             import torch.distributed as dist
 
-            key = torch.tensor([local_key], dtype=torch.int64, device=_collective_device(device, self.group))
+            # second word: does this rank hold a finished trial whose shapes can serve as the broadcast layout?  (A rank whose
+            # trials were all interrupted, or one of more ranks than trials, does not.)
+            key = torch.tensor([local_key, 1 if len(local_solutions) > 0 else 0], dtype=torch.int64,
+                               device=_collective_device(device, self.group))
             dist.all_reduce(key, op=dist.ReduceOp.MIN, group=self.group)  # the single selection collective
-            best_key = int(key.item())
+            best_key, every_rank_has_a_template = (int(v) for v in key.tolist())
         value, trial = unpack_key(best_key)
         if trial == 0xFFFFFFFF or trial >= self.num_trials:
             # no rank produced a solution (interrupted before the first trial finished)
             raise RuntimeError("No trial finished; nothing to select.")
 
-        if self.world == 1:
+        if not collective:
             solution = local_solutions[trial]
         else:
-            solution = self._broadcast_solution(local_solutions, trial, device)
+            solution = self._broadcast_solution(local_solutions, trial, device, bool(every_rank_has_a_template))
             if gather_stats:
                 self._merge_stats(stats)
         return value, solution
 
     # -- distributed helpers ---------------------------------------------------------------------------------------
-    def _broadcast_solution(self, local_solutions, trial, device):
-        """One broadcast: the parts of the winning solution, flattened into one fp32 buffer.  The layout comes from any
-        local solution (all trials of an attack have the same shapes).  Only a rank without a single finished trial -- more
-        ranks than trials -- needs the shapes sent first; that rare case costs one extra host-side object broadcast, which
-        every rank then takes part in (the all-reduced flag below tells them)."""
+    def _broadcast_solution(self, local_solutions, trial, device, every_rank_has_a_template=True):
+        """One broadcast: the parts of the winning solution, flattened into one buffer of their common dtype (fp32 for every
+        supported attack; parts of another dtype -- an fp64 set-up, integer label parts -- travel in one more buffer per
+        dtype, unrounded).  The layout comes from any local solution (all trials of an attack have the same shapes).  Only
+        when some rank holds no finished trial (more ranks than trials, or a rank interrupted before its first trial
+        ended: the flag all-reduced together with the key says so on every rank) are the shapes sent first, by one host-side
+        object broadcast that every rank then takes part in."""
         import torch.distributed as dist
 
         src = self.owner(trial)
         cdev = _collective_device(device, self.group)
-        template = next(iter(local_solutions.values())) if len(local_solutions) > 0 else None
-        if self.world > self.num_trials:  # some rank may hold no template: agree on the shapes the slow way
+        if not every_rank_has_a_template:
             meta = [None]
             if self.rank == src:
                 sol = local_solutions[trial]
@@ -118,20 +126,26 @@ class TrialShard:
             dist.broadcast_object_list(meta, src=_global_rank(src, self.group), group=self.group)
             *shapes, is_single = meta[0]
         else:
+            template = next(iter(local_solutions.values()))
             parts = [template] if torch.is_tensor(template) else list(template)
             shapes = [(tuple(p.shape), str(p.dtype).replace("torch.", "")) for p in parts]
             is_single = torch.is_tensor(template)
         sizes = [int(torch.Size(shape).numel()) for shape, _ in shapes]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=cdev)
         if self.rank == src:
             sol = local_solutions[trial]
             parts = [sol] if torch.is_tensor(sol) else list(sol)
-            torch.cat([p.detach().reshape(-1).to(device=cdev, dtype=torch.float32) for p in parts], out=flat)
-        dist.broadcast(flat, src=_global_rank(src, self.group), group=self.group)  # the single winner broadcast
-        out, offset = [], 0
-        for (shape, dtype), n in zip(shapes, sizes):
-            out.append(flat[offset : offset + n].view(shape).to(device=device, dtype=getattr(torch, dtype)))
-            offset += n
+        out = [None] * len(shapes)
+        for dtype_name in dict.fromkeys(dtype for _, dtype in shapes):  # one flat buffer per dtype, in order of appearance
+            members = [i for i, (_, dtype) in enumerate(shapes) if dtype == dtype_name]
+            dtype = getattr(torch, dtype_name)
+            flat = torch.empty(sum(sizes[i] for i in members), dtype=dtype, device=cdev)
+            if self.rank == src:
+                torch.cat([parts[i].detach().reshape(-1).to(device=cdev, dtype=dtype) for i in members], out=flat)
+            dist.broadcast(flat, src=_global_rank(src, self.group), group=self.group)  # the single winner broadcast
+            offset = 0
+            for i in members:
+                out[i] = flat[offset : offset + sizes[i]].view(shapes[i][0]).to(device=device)
+                offset += sizes[i]
         return out[0] if is_single else tuple(out)
 
     def _merge_stats(self, stats):
@@ -139,11 +153,13 @@ class TrialShard:
 
         mine = {k: v for k, v in stats.items() if k.startswith("Trial_")}
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, mine, group=self.group)
-        for other in gathered:
+        dist.all_gather_object(gathered, (mine, stats.get("execution_trials")), group=self.group)
+        for other, execution in gathered:
             for k, v in other.items():
                 if k not in stats or len(stats[k]) == 0:
                     stats[k] = v
+            if execution is not None:  # how each rank issued its trials (hipGraph replay / eager launches)
+                stats.setdefault("execution_trials", {}).update(execution)
 
 
 def _to_float(score):
@@ -166,3 +182,56 @@ def _global_rank(group_rank, group):
     if group is None:
         return group_rank
     return dist.get_global_rank(group, group_rank)
+
+
+def dry_collective(device, backend="nccl", timeout_s=120.0):
+    """Run the selection's two collectives -- int64 `all_reduce(MIN)` on the packed key, flat broadcast of the winner -- on
+    DEVICE tensors through a ONE-rank process group of `backend` ("nccl" = RCCL accepts a one-rank communicator).  This is
+    what a 1-GPU box can execute of the multi-GPU path: communicator creation, both collectives and the teardown go through
+    RCCL exactly as they will at 2 / 4 / 8 ranks.  Must run in a process without a default process group.  Returns a record
+    of what ran."""
+    import datetime
+    import os
+    import socket
+    import time
+
+    import torch.distributed as dist
+
+    device = torch.device(device)
+    if dist.is_initialized():
+        raise RuntimeError("dry_collective needs a process without a default process group")
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    kwargs = dict(device_id=device) if backend == "nccl" else {}
+    t0 = time.perf_counter()
+    dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+    try:
+        shard = TrialShard(3, rank=0, world=1, always_collective=True)
+        solutions = {t: (torch.full((1, 3, 8, 8), float(t), device=device), torch.full((1, 5), -float(t), device=device))
+                     for t in range(3)}
+        scores = {0: torch.tensor(0.75, device=device), 1: torch.tensor(0.25, device=device), 2: float("nan")}
+        stats = {f"Trial_{t}_Val": [float(t)] for t in range(3)}
+        t1 = time.perf_counter()
+        value, solution = shard.select(solutions, scores, stats, device)
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        ok = (value == 0.25 and solution[0].device.type == device.type and float(solution[0].flatten()[0]) == 1.0
+              and float(solution[1].flatten()[0]) == -1.0 and sorted(stats) == [f"Trial_{t}_Val" for t in range(3)])
+        return dict(backend=dist.get_backend(), world=dist.get_world_size(), device=str(device), ok=bool(ok), value=value,
+                    init_s=round(t1 - t0, 3), select_s=round(t2 - t1, 3))
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":  # python -m breaching_amd.trials --dry-collective [nccl|gloo] [device]
+    import json
+    import sys
+
+    if len(sys.argv) >= 2 and sys.argv[1] == "--dry-collective":
+        backend = sys.argv[2] if len(sys.argv) > 2 else "nccl"
+        device = sys.argv[3] if len(sys.argv) > 3 else ("cuda:0" if backend == "nccl" else "cpu")
+        print(json.dumps(dry_collective(device, backend)))

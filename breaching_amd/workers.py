@@ -11,33 +11,67 @@ of ``trials.TrialShard.select``.  The rendezvous (RCCL unique id included) goes 
 reference: the sequential trial loop of breaching/attacks/optimization_based_attack.py:70-78 -- the reference has no
 multi-device code, this is an MI355X-native addition behind the unchanged ``reconstruct`` signature.
 
-Protocol (one duplex pipe per worker):  parent -> worker ``("job", dict)`` | ``("stop",)``;  worker -> parent
-``("ready",)`` once its process group is up, ``("trials_done",)`` when its trials are finished -- it then waits for
-``("go",)`` from the parent before entering the selection collective -- ``("ok",)`` when the job is finished,
-``("error", traceback)`` on failure.  The parent sends ``go`` only after every worker reported ``trials_done``: all ranks
-enter the collective within milliseconds of each other (no rank sits in RCCL while another still optimises, so the
-collective watchdog never fires), and a crashed worker raises in the parent instead of hanging it.
+Protocol (one duplex pipe per worker):  parent -> worker ``("job", dict)`` | ``("go",)`` | ``("abort",)`` | ``("stop",)``;
+worker -> parent ``("booted",)`` as the first statement of the child (its arguments unpickled, i.e. the victim model class is
+importable there), ``("ready",)`` once its process group is up, ``("trials_done",)`` when its trials are finished -- it then
+waits for ``("go",)`` from the parent before entering the selection collective -- ``("ok",)`` when the job is finished,
+``("error", traceback)`` on failure, ``("aborted",)`` in answer to ``abort``.  The parent sends ``go`` only after every
+worker reported ``trials_done``: all ranks enter the collective within milliseconds of each other (no rank sits in RCCL while
+another still optimises, so a short collective timeout is safe), and a crashed worker raises in the parent instead of
+hanging it.  When a job fails anywhere between ``submit`` and the last ``ok`` -- a worker error, or rank 0's own trials
+raising -- the parent calls ``abort()``: every worker leaves the job (the ones waiting for ``go`` raise `JobAborted`
+instead of entering a collective nobody else will join), acknowledges, and the pool is clean for the next call; workers that
+do not acknowledge within ``drain_timeout`` are killed and the pool is closed (the next ``reconstruct`` starts a new one).
 """
 
 import logging
 import os
 import socket
 import traceback
+import weakref
 
 import torch
 
 log = logging.getLogger(__name__)
 
+# Collectives are entered only after every rank reported `trials_done` (see the protocol above), so a rank never waits in
+# one for longer than the others need to get there: seconds.  The same limit bounds the start-up rendezvous.
+DEFAULT_COLLECTIVE_TIMEOUT = 180.0
 
-_ACTIVE_POOL = None
+_ACTIVE_POOL = None  # weak reference: a pool dies with the attacker that owns it
+
+
+class JobAborted(Exception):
+    """Raised inside a worker's job when the parent cancels it at the rendezvous."""
 
 
 def active_pool():
     """The worker pool that owns this process's default process group, or None.  While a pool is idle (no job submitted),
     `torch.distributed.is_initialized()` is true although nobody else will join a collective -- callers that did not submit
     work to the pool must not shard over that group."""
-    pool = _ACTIVE_POOL
+    pool = _ACTIVE_POOL() if _ACTIVE_POOL is not None else None
     return pool if pool is not None and not getattr(pool, "closed", True) else None
+
+
+def rendezvous(conn):
+    """Worker side of the barrier in front of the selection collective: report `trials_done`, wait for `go`."""
+    conn.send(("trials_done",))
+    message = conn.recv()
+    if message[0] == "abort":
+        raise JobAborted()
+    if message[0] != "go":
+        raise RuntimeError(f"trial worker protocol error: expected 'go', got {message[0]!r}")
+
+
+def to_device(obj, device):
+    """Nested lists / tuples / dicts with every tensor moved to `device` (containers are rebuilt, other leaves shared)."""
+    if torch.is_tensor(obj):
+        return obj.to(device)
+    if isinstance(obj, dict):
+        return type(obj)((k, to_device(v, device)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to_device(v, device) for v in obj)
+    return obj
 
 
 def free_port():
@@ -77,27 +111,38 @@ def requested_devices(cfg, device):
     return devices
 
 
-def _worker_main(rank, world, port, backend, device_index, conn, runner_factory, factory_args):
+def _worker_main(rank, world, port, backend, device_index, conn, runner_factory, factory_args, timeout):
     """Entry point of rank `rank` > 0."""
+    import datetime
+
     import torch.distributed as dist
 
     try:
+        conn.send(("booted",))  # the spawn bootstrap unpickled our arguments: the parent may start its own rendezvous
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         if device_index is not None:
             torch.cuda.set_device(device_index)
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", device_index)
-        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout), **kwargs)
         runner = runner_factory(rank, world, device_index, conn, *factory_args)
         conn.send(("ready",))
         while True:
             message = conn.recv()
             if message[0] == "stop":
                 break
+            if message[0] == "abort":  # the job this refers to is already over here (finished or failed): acknowledge
+                conn.send(("aborted",))
+                continue
+            if message[0] != "job":  # e.g. a `go` that crossed an error report
+                continue
             try:
                 runner(message[1])
                 conn.send(("ok",))
+            except JobAborted:
+                conn.send(("aborted",))
             except Exception:  # report and stay alive for the next job
                 conn.send(("error", traceback.format_exc()))
         dist.destroy_process_group()
@@ -113,7 +158,8 @@ def _worker_main(rank, world, port, backend, device_index, conn, runner_factory,
 class TrialWorkerPool:
     """W - 1 persistent worker processes plus the calling process as rank 0 of one process group."""
 
-    def __init__(self, devices, runner_factory, factory_args=(), backend=None, start_timeout=600.0):
+    def __init__(self, devices, runner_factory, factory_args=(), backend=None, start_timeout=None, collective_timeout=None,
+                 drain_timeout=15.0):
         import datetime
 
         import torch.distributed as dist
@@ -129,21 +175,33 @@ class TrialWorkerPool:
             on_gpu = all(d is not None for d in self.devices)
             backend = "nccl" if on_gpu and len(set(self.devices)) == self.world else "gloo"
         self.backend = backend
+        if collective_timeout is None:
+            collective_timeout = float(os.environ.get("BREACH_HIP_COLLECTIVE_TIMEOUT", DEFAULT_COLLECTIVE_TIMEOUT))
+        self.collective_timeout = float(collective_timeout)
+        start_timeout = self.collective_timeout if start_timeout is None else float(start_timeout)
+        self.drain_timeout = float(drain_timeout)
+        self.busy = False  # a job is in flight (between submit and the last `ok`)
         self.port = free_port()
         ctx = mp.get_context("spawn")
         self.workers = []
         for rank in range(1, self.world):
             parent_end, child_end = ctx.Pipe(duplex=True)
             proc = ctx.Process(target=_worker_main, daemon=True,
-                               args=(rank, self.world, self.port, backend, self.devices[rank], child_end, runner_factory, factory_args))
+                               args=(rank, self.world, self.port, backend, self.devices[rank], child_end, runner_factory,
+                                     factory_args, self.collective_timeout))
             proc.start()
             child_end.close()
             self.workers.append((proc, parent_end))
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(self.port)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", self.devices[0])
         try:
+            # A child that cannot even start (its arguments do not unpickle there: an unimportable victim model class) dies
+            # in the spawn bootstrap; `_collect` polls `is_alive`, so that is noticed here in a fraction of a second and
+            # not after the rendezvous timeout below.
+            self.expect("booted", start_timeout)
             dist.init_process_group(backend, rank=0, world_size=self.world,
                                     timeout=datetime.timedelta(seconds=start_timeout), **kwargs)
             for message in self._collect(start_timeout):
@@ -154,14 +212,50 @@ class TrialWorkerPool:
             raise
         self.closed = False
         global _ACTIVE_POOL
-        _ACTIVE_POOL = self
-        log.info(f"Trial worker pool up: {self.world} ranks on devices {self.devices} ({backend}).")
+        _ACTIVE_POOL = weakref.ref(self)
+        log.info(f"Trial worker pool up: {self.world} ranks on devices {self.devices} ({backend}, collective timeout "
+                 f"{self.collective_timeout:.0f} s).")
+
+    def describe(self):
+        """What a caller gets to see in `stats["trial_pool"]`."""
+        return dict(backend=self.backend, world=self.world, devices=list(self.devices))
 
     # -- messaging -------------------------------------------------------------------------------------------------
     def submit(self, jobs):
         """`jobs[r - 1]` goes to rank r."""
+        self.busy = True
         for (proc, conn), job in zip(self.workers, jobs):
             conn.send(("job", job))
+
+    def finish(self):
+        """Every worker reported `ok`: the job is over."""
+        self.expect("ok")
+        self.busy = False
+
+    def abort(self):
+        """Cancel the job in flight after a failure on any rank: workers waiting for `go` leave the job instead of entering
+        the collective, every worker acknowledges, and whatever else they had sent for that job (`trials_done`, `error`,
+        `ok`) is discarded -- so the next `submit` starts from a clean pipe.  Workers that do not acknowledge within
+        `drain_timeout` (still optimising, or stuck in a collective rank 0 never joined) are killed with the pool."""
+        import time
+
+        if getattr(self, "closed", True):
+            return
+        deadline = time.time() + self.drain_timeout
+        try:
+            for proc, conn in self.workers:
+                conn.send(("abort",))
+            for idx, (proc, conn) in enumerate(self.workers):
+                while True:
+                    remaining = deadline - time.time()
+                    if remaining <= 0 or not proc.is_alive():
+                        raise TimeoutError(f"trial worker (rank {idx + 1}) did not acknowledge the abort")
+                    if conn.poll(min(remaining, 0.2)) and conn.recv()[0] == "aborted":  # EOFError: handled below
+                        break
+            self.busy = False
+        except Exception as exc:
+            log.warning(f"Trial worker pool could not be drained after a failed job ({exc!r}); closing it.")
+            self.close(force=True)
 
     def broadcast(self, message):
         for proc, conn in self.workers:
@@ -178,7 +272,11 @@ class TrialWorkerPool:
                 if out[idx] is not None:
                     continue
                 if conn.poll(poll):
-                    message = conn.recv()
+                    try:
+                        message = conn.recv()
+                    except (EOFError, ConnectionError):  # the child closed its end: it is gone
+                        proc.join(timeout=5.0)
+                        raise RuntimeError(f"trial worker (rank {idx + 1}) died with exit code {proc.exitcode}") from None
                     if message[0] == "error":
                         raise RuntimeError(f"trial worker (rank {idx + 1}) failed:\n{message[1]}")
                     out[idx] = message
@@ -200,7 +298,8 @@ class TrialWorkerPool:
         if getattr(self, "closed", False):
             return
         self.closed = True
-        if _ACTIVE_POOL is self:
+        self.busy = False
+        if _ACTIVE_POOL is not None and _ACTIVE_POOL() in (self, None):
             _ACTIVE_POOL = None
         for proc, conn in self.workers:
             try:
@@ -236,17 +335,16 @@ def attacker_runner_factory(rank, world, device_index, conn, attack_class_name, 
     att = getattr(attacker_module, attack_class_name)(model, loss_fn, cfg, dict(device=device, dtype=torch.float))
     att._is_trial_worker = True
 
-    def rendezvous():
-        conn.send(("trials_done",))
-        message = conn.recv()
-        if message[0] != "go":
-            raise RuntimeError(f"trial worker protocol error: expected 'go', got {message[0]!r}")
-
     def run(job):
         att._preset = dict(inits=job["inits"], labels=job["labels"])
-        att._before_select = rendezvous
+        att._before_select = lambda: rendezvous(conn)
         try:
-            att.reconstruct(job["server_payload"], job["shared_data"], job["server_secrets"], job["initial_data"], job["dryrun"])
+            # Everything tensor-valued moves to this rank's device up front -- the reference only casts gradients and
+            # buffers (base_attack.py:214-220) because its caller's tensors already live on the attack device; here
+            # they arrive as host copies, and e.g. the FedAvg labels in metadata.local_hyperparams are used as they are.
+            shared_data = to_device(job["shared_data"], device)
+            server_secrets = to_device(job["server_secrets"], device)
+            att.reconstruct(job["server_payload"], shared_data, server_secrets, job["initial_data"], job["dryrun"])
         finally:
             att._preset, att._before_select = None, None
 

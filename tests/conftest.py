@@ -14,9 +14,46 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm GPU (run with `-m gpu` on the MI355X box)")
 
 
+# Collection order: the cheap, deterministic, oracle-anchored tests run FIRST, the end-to-end
+# trajectories of chaotic configurations LAST -- under `-x` a wobble in a long trajectory must not blank kernel parity.
+_MODULE_ORDER = ["test_abi", "test_oracle_pinning", "test_host_logic", "test_workers", "test_gpu_kernels", "test_gpu_runtime",
+                 "test_gpu_attack", "test_gpu_baseline_configs"]
+
+
+def _module_rank(item):
+    name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+    return _MODULE_ORDER.index(name) if name in _MODULE_ORDER else len(_MODULE_ORDER)
+
+
+# Run-vs-run comparisons of OUR OWN attack (hipGraph replay vs eager launches, trials in flight vs sequential, worker pool
+# vs one rank).  On the boxes measured in round 3 such runs are bit-identical (profiles/r3_mode_spread_convnet.json: 3 eager
+# and 3 graph runs, default and deterministic MIOpen mode, every iterate equal), but the vendor kernels of the victim's double
+# backward give no such guarantee: the driver's round-2 box produced an eager run whose 15-iteration opt_value sat 4.5e-5
+# (relative) away from the graph run's.  A replay / scheduling defect (stale scalar, missed best copy, wrong iteration count)
+# shows at the percent level, so these limits -- north_star's 1e-4 on the trajectory, 20x the observed wobble on the rescored
+# optimum, 1e-3 on >= 99.9 % of the pixels -- still catch it.
+RUN_VS_RUN = dict(history_rtol=1e-4, opt_value_rel=1e-3, pixel_tol=1e-3, pixel_fraction=0.999)
+
+
+def assert_same_attack(run_a, run_b, stats_keys=None):
+    """`run_x = (reconstruction tensor, stats)` of two executions of the same attack from the same start."""
+    import numpy as np
+
+    (rec_a, stats_a), (rec_b, stats_b) = run_a, run_b
+    keys = stats_keys if stats_keys is not None else sorted(k for k in stats_a if k.startswith("Trial_"))
+    assert keys and sorted(k for k in stats_b if k.startswith("Trial_")) == sorted(k for k in stats_a if k.startswith("Trial_"))
+    for key in keys:
+        np.testing.assert_allclose(stats_a[key], stats_b[key], rtol=RUN_VS_RUN["history_rtol"], err_msg=key)
+    assert stats_a["opt_value"] == pytest.approx(stats_b["opt_value"], rel=RUN_VS_RUN["opt_value_rel"])
+    a, b = rec_a.detach().cpu().numpy(), rec_b.detach().cpu().numpy()
+    close = np.isclose(a, b, rtol=RUN_VS_RUN["pixel_tol"], atol=RUN_VS_RUN["pixel_tol"]).mean()
+    assert close >= RUN_VS_RUN["pixel_fraction"], close
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
 
+    items.sort(key=_module_rank)  # stable: the order inside a module stays as written
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason="no ROCm GPU visible")

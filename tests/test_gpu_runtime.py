@@ -1,0 +1,61 @@
+"""Runtime behaviour around the kernels on the GPU box: the RCCL code path of the trial selection on one rank, hipGraph
+capture policy, one process running attack after attack (the reference's benchmark_breaches.py:60-70 pattern)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_selection_collectives_run_through_rccl_on_one_rank():
+    """`all_reduce(MIN)` on the packed int64 key + the flat winner broadcast + the stats gather, on device tensors, through a
+    ONE-rank "nccl" (= RCCL) process group: communicator creation, both collectives and teardown are the code the 2 / 4 / 8
+    GPU runs execute.  In a subprocess: the pytest process keeps no process group, and a hung
+    communicator start cannot hang the suite."""
+    proc = subprocess.run([sys.executable, "-m", "breaching_amd.trials", "--dry-collective", "nccl", "cuda:0"], cwd=ROOT,
+                          capture_output=True, text=True, timeout=240)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    record = json.loads(proc.stdout.strip().splitlines()[-1])
+    print(" ", record)
+    assert record["backend"] == "nccl" and record["world"] == 1 and record["device"] == "cuda:0"
+    assert record["ok"] and record["value"] == 0.25
+
+
+def test_capture_failure_is_an_error_unless_the_policy_is_auto(monkeypatch):
+    """impl.hip_graph=True (default): a failed capture raises; "auto": eager launches with the reason in stats["execution"];
+    False: never captured."""
+    import breaching_amd
+    from breaching_amd import attacker as attacker_module
+    from breaching_amd.cases import build_case, initial_candidate
+
+    case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
+    x0 = initial_candidate(case.data_cfg, 1, seed=6)
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float)
+
+    class _Broken:
+        def __init__(self, *a, **k):
+            raise RuntimeError("capture refused")
+
+    def run(flag):
+        cfg = breaching_amd.get_attack_config("invertinggradients", ["optim.max_iterations=6", "optim.callback=3", f"impl.hip_graph={flag}"])
+        att = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
+        return att.reconstruct(case.server_payload, case.shared_data, {}, initial_data=x0)
+
+    _, healthy = run("True")
+    assert healthy["execution"]["trials"] == {0: "hipGraph replay"}
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", _Broken)
+    with pytest.raises(RuntimeError, match="hipGraph capture of the attack iteration failed"):
+        run("True")
+    _, stats = run("auto")
+    assert stats["execution"]["trials"][0].startswith("eager launches (capture failed: RuntimeError('capture refused')")
+    np.testing.assert_allclose(stats["Trial_0_Val"], healthy["Trial_0_Val"], rtol=1e-4)
+    _, stats = run("False")
+    assert stats["execution"]["trials"] == {0: "eager launches (graph replay switched off)"}

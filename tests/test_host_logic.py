@@ -59,6 +59,42 @@ def _free_port():
     return port
 
 
+def _worker_ragged(rank, world, port, out_dir):
+    """Rank 1 finished no trial although it owns some (interrupted before its first trial ended); the solution parts are
+    fp64 data and int64 labels -- neither may be rounded through an fp32 buffer."""
+    import torch.distributed as dist
+
+    from breaching_amd.trials import TrialShard
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shard = TrialShard.current(4)
+        sols, scores, stats = {}, {}, {}
+        if rank == 0:
+            for t in shard.local_trials():
+                sols[t] = (torch.full((1, 3), 1.0 + 2.0 ** -40 * (t + 1), dtype=torch.float64),
+                           torch.full((1, 2), 2 ** 40 + t, dtype=torch.int64))
+                scores[t] = [0.75, None, 0.5][t]
+                stats[f"Trial_{t}_Val"] = [float(t)]
+        value, sol = shard.select(sols, scores, stats, torch.device("cpu"))
+        torch.save(dict(value=value, data=sol[0], labels=sol[1], stats=stats), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_selection_when_a_rank_finished_no_trial_and_parts_are_not_fp32(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker_ragged, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        out = torch.load(tmp_path / f"rank{r}.pt", weights_only=False)
+        assert out["value"] == 0.5
+        assert out["data"].dtype == torch.float64 and out["data"].tolist() == [[1.0 + 2.0 ** -40 * 3] * 3]
+        assert out["labels"].dtype == torch.int64 and out["labels"].tolist() == [[2 ** 40 + 2] * 2]
+        assert sorted(out["stats"]) == ["Trial_0_Val", "Trial_2_Val"]
+
+
 def _worker(rank, world, port, num_trials, out_dir):
     import torch.distributed as dist
 

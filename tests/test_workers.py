@@ -19,11 +19,23 @@ def _runner_factory(rank, world, device_index, conn, num_trials):
         solutions = {t: torch.full((2, 3), float(t)) for t in shard.local_trials()}
         scores = {t: job["scores"][t] for t in shard.local_trials()}
         stats = {f"Trial_{t}_Val": [float(t)] * 3 for t in shard.local_trials()}
-        conn.send(("trials_done",))
-        assert conn.recv()[0] == "go"
+        from breaching_amd.workers import rendezvous
+
+        rendezvous(conn)  # trials_done -> go (or JobAborted)
         shard.select(solutions, scores, stats, torch.device("cpu"))
 
     return run
+
+
+def _unpickle_bomb():
+    raise ImportError("victim model class is not importable in the worker")
+
+
+class _Bomb:
+    """Pickles fine in the parent, fails to unpickle in the spawned child -- what an unimportable model class does."""
+
+    def __reduce__(self):
+        return (_unpickle_bomb, ())
 
 
 def test_pool_runs_jobs_selects_and_survives_errors():
@@ -51,15 +63,59 @@ def test_pool_runs_jobs_selects_and_survives_errors():
             want_value, want_trial = min(finite)
             assert value == want_value and float(solution[0, 0]) == float(want_trial)
             assert sorted(stats) == [f"Trial_{t}_Val" for t in range(num_trials)]  # every rank's histories merged
-        # a failing worker reports its traceback; the parent raises instead of waiting in the collective
+        # a failing worker reports its traceback; the parent raises instead of waiting in the collective ...
         pool.submit([dict(scores=[1.0] * 5, explode=2)] * 2)
         with pytest.raises(RuntimeError, match="boom"):
             pool.expect("trials_done")
+        # ... and cancels the job: rank 1 (healthy, waiting for `go`) leaves it without entering the collective, rank 2's
+        # error report is discarded, and the SAME pool runs the next job cleanly (what `reconstruct` does on any failure)
+        assert pool.busy
+        pool.abort()
+        assert not pool.closed and not pool.busy
+        scores = [4.0, 2.0, 0.5, 1.0, 3.0]
+        pool.submit([dict(scores=scores)] * 2)
+        shard = trials.TrialShard.current(num_trials)
+        solutions = {t: torch.full((2, 3), float(t)) for t in shard.local_trials()}
+        pool.expect("trials_done")
+        pool.broadcast(("go",))
+        value, solution = shard.select(solutions, {t: scores[t] for t in shard.local_trials()}, {}, torch.device("cpu"))
+        pool.finish()
+        assert value == 0.5 and float(solution[0, 0]) == 2.0 and not pool.busy
+        # rank 0's own failure before any worker finished: abort drains a pool whose workers are all waiting for `go`
+        pool.submit([dict(scores=scores)] * 2)
+        pool.abort()
+        assert not pool.closed
     finally:
         pool.close(force=True)
     import torch.distributed as dist
 
     assert workers.active_pool() is None and not dist.is_initialized()  # the group never outlives its pool
+
+
+def test_pool_start_fails_fast_when_a_child_cannot_boot_and_pool_dies_with_its_owner():
+    """A child whose arguments do not unpickle (an unimportable victim model class) is noticed through `is_alive` within
+    seconds, not after the rendezvous timeout; the module-level handle on the active pool is weak."""
+    import gc
+    import time
+
+    import torch.distributed as dist
+
+    from breaching_amd import workers
+    from breaching_amd.workers import TrialWorkerPool
+
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="died"):
+        TrialWorkerPool([None, None], _runner_factory, (_Bomb(),), collective_timeout=120.0)
+    assert time.time() - t0 < 60.0
+    assert workers.active_pool() is None and not dist.is_initialized()
+
+    pool = TrialWorkerPool([None, None], _runner_factory, (2,))
+    assert workers.active_pool() is pool
+    procs = [proc for proc, _ in pool.workers]
+    del pool
+    gc.collect()
+    assert workers.active_pool() is None and not dist.is_initialized()
+    assert all(not proc.is_alive() for proc in procs)
 
 
 def test_requested_devices_parsing(monkeypatch):
