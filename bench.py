@@ -154,8 +154,13 @@ def main():
             m.to(memory_format=torch.channels_last)
         x0 = x0.contiguous(memory_format=torch.channels_last)
     x0 = x0.requires_grad_(True)
-    run = FusedTrial(attacker, [x0], labels, rec_models, case.shared_data)
-    # further restarts on their own streams (same path as HipOptimizationAttacker._run_trial_group)
+    # One trial: on the caller's stream, like `_fused_loop`.  Several in flight: every one on a side stream of its own, none on
+    # the caller's (same layout as HipOptimizationAttacker._run_trial_group, see the measurement quoted there).
+    main_stream = torch.cuda.current_stream(device)
+    first_stream = torch.cuda.Stream(device) if args.trials_per_gpu > 1 else main_stream
+    first_stream.wait_stream(main_stream)
+    with torch.cuda.stream(first_stream):
+        run = FusedTrial(attacker, [x0], labels, rec_models, case.shared_data)
     extra = []
     for j in range(1, args.trials_per_gpu):
         stream = torch.cuda.Stream(device)
@@ -165,7 +170,8 @@ def main():
             extra.append((stream, FusedTrial(attacker, [xj], labels, rec_models, case.shared_data)))
 
     def step_all():
-        run.step()
+        with torch.cuda.stream(first_stream):
+            run.step()
         for stream, other in extra:
             with torch.cuda.stream(stream):
                 other.step()
@@ -211,13 +217,15 @@ def main():
     eager_ms = None
     if plan is not None and not args.no_kernel_timing and not timed_with_events:
         run.disable_graph()
-        for _ in range(3):
-            run.step()
+        with torch.cuda.stream(first_stream):
+            for _ in range(3):
+                run.step()
         plan.enable_timing()
         barrier()
         te = time.perf_counter()
-        for _ in range(args.roofline_steps):
-            run.step()
+        with torch.cuda.stream(first_stream):
+            for _ in range(args.roofline_steps):
+                run.step()
         barrier()
         eager_ms = (time.perf_counter() - te) / max(args.roofline_steps, 1) * 1e3
 
@@ -298,9 +306,9 @@ def main():
         try:
             proc = subprocess.run([sys.executable, "-m", "breaching_amd.trials", "--dry-collective", "nccl", str(device)], cwd=ROOT,
                                   capture_output=True, text=True, timeout=150)
-            last = proc.stdout.strip().splitlines()[-1] if proc.stdout.strip() else ""
-            rccl_dry_run = json.loads(last) if proc.returncode == 0 and last.startswith("{") else dict(
-                ok=False, returncode=proc.returncode, stderr=proc.stderr[-400:])
+            rccl_dry_run = trials.parse_dry_collective(proc.stdout) if proc.returncode == 0 else None
+            if rccl_dry_run is None:
+                rccl_dry_run = dict(ok=False, returncode=proc.returncode, stdout=proc.stdout[-300:], stderr=proc.stderr[-400:])
         except Exception as exc:  # a timeout included: reported, never fatal for the measurement
             rccl_dry_run = dict(ok=False, error=repr(exc))
 

@@ -613,18 +613,20 @@ class HipOptimizationAttacker:
                 if isinstance(module, _EvalAffineBatchNorm2d) and not module.training and module.running_var is not None:
                     module._frozen_statistics()
         main = torch.cuda.current_stream(device)
-        # The first trial stays on the caller's stream: HIP multiplexes streams onto 4 hardware queues and the caller's
-        # stream already holds one, so 1 + 3 side streams is the layout that gives every trial in flight its own queue.
-        import os
-        keep_main = os.environ.get("BREACH_HIP_GROUP_MAIN_STREAM", "1") != "0"
-        streams = {t: (main if (i == 0 and keep_main) else torch.cuda.Stream(device)) for i, t in enumerate(group)}
+        # EVERY trial of the group gets a side stream of its own; none runs on the caller's stream.  Measured (round 3,
+        # profiles/r3_stall_bisect.jsonl): once an earlier attack of the process has replayed a hipGraph on the caller's
+        # stream (the legacy null stream in simulate_breach.py / benchmark_breaches.py), a group with one trial on that
+        # stream and three on side streams runs at ~120 iterations/s instead of ~430 -- every replay then serialises against
+        # the other trials' streams; with all four on side streams the rate is 428 whether or not an attack ran before
+        # (and the same 430-440 in a fresh process).  GPU_MAX_HW_QUEUES=8 (breaching_amd/__init__.py) leaves a hardware
+        # queue for each of them next to the caller's.
+        streams = {t: torch.cuda.Stream(device) for t in group}
         runs = {}
         for t in group:
             candidates = list(init_states[t])
             if initial_data is not None:
                 candidates[0].data = initial_data.data.clone().to(**self.setup).contiguous()
-            if streams[t] is not main:
-                streams[t].wait_stream(main)
+            streams[t].wait_stream(main)
             with torch.cuda.stream(streams[t]):
                 runs[t] = FusedTrial(self, candidates, labels, rec_model, shared_data)
         current_wallclock = time.time()
@@ -659,8 +661,7 @@ class HipOptimizationAttacker:
                 best = runs[t].best()
                 self.last_trial_execution = runs[t].execution_mode()
                 self._record_execution(t, self.last_trial_execution)
-            if streams[t] is not main:
-                main.wait_stream(streams[t])
+            main.wait_stream(streams[t])
             solutions[t] = best[0] if len(best) == 1 else tuple(best)
         return solutions
 

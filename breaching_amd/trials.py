@@ -227,6 +227,16 @@ def dry_collective(device, backend="nccl", timeout_s=120.0):
         dist.destroy_process_group()
 
 
+def parse_dry_collective(stdout):
+    """The record printed by ``python -m breaching_amd.trials --dry-collective`` out of a captured stdout (None if absent)."""
+    import json
+
+    for line in reversed(stdout.splitlines()):
+        if line.startswith("DRY_COLLECTIVE "):
+            return json.loads(line[len("DRY_COLLECTIVE "):])
+    return None
+
+
 if __name__ == "__main__":  # python -m breaching_amd.trials --dry-collective [nccl|gloo] [device]
     import json
     import sys
@@ -234,4 +244,5 @@ if __name__ == "__main__":  # python -m breaching_amd.trials --dry-collective [n
     if len(sys.argv) >= 2 and sys.argv[1] == "--dry-collective":
         backend = sys.argv[2] if len(sys.argv) > 2 else "nccl"
         device = sys.argv[3] if len(sys.argv) > 3 else ("cuda:0" if backend == "nccl" else "cpu")
-        print(json.dumps(dry_collective(device, backend)))
+        # one marked line: RCCL / gloo write their own chatter to stdout around it
+        print("DRY_COLLECTIVE " + json.dumps(dry_collective(device, backend)), flush=True)

@@ -184,6 +184,7 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
  * host array of device pointers (kernel arguments, at most BH_BN_MAX_LAYERS), their geometry in a device table. */
 #define BH_BN_MAX_LAYERS 448
 #define BH_BN_TILE 4096 /* elements per backward work item */
+#define BH_BN_DEFAULT_GRID 2048 /* persistent forward grid: workgroups resident at once (8 per CU on 256 CUs) */
 
 typedef struct bh_bn_layer { /* 64 bytes, device resident, built once per attack by bh_bn_plan_build */
   int64_t flat_off;      /* element offset of the layer inside the packed gradient buffer (multiple of 4) */
@@ -210,11 +211,14 @@ int bh_bn_plan_build(int32_t n_layers, const int32_t* B, const int32_t* C, const
                      bh_bn_layer* layers, bh_bn_item* fwd_items, int64_t n_fwd_items, bh_bn_item* bwd_items,
                      int64_t n_bwd_items);
 
-/* Stage 1: per-channel sum and sum of squares of every layer, one workgroup per forward item, into
- * sums_dev[2 * n_sum_pairs] doubles (overwritten).  `x_ptrs` / `hw_host`: HOST arrays (device pointers, HW per layer).
+/* Stage 1: per-channel sum and sum of squares of every layer -- a persistent grid of at most BH_BN_DEFAULT_GRID workgroups
+ * (bh_bn_set_grid_cap) streams the forward items -- into sums_dev[2 * n_sum_pairs] doubles (overwritten).  `x_ptrs` / `hw_host`: HOST arrays (device pointers, HW per layer).
  * reference: deepinversion.py:93-96 (mean / biased var of the BN input). */
 int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
                const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, void* stream);
+
+/* Tuning knob of stage 1 (process wide, default BH_BN_DEFAULT_GRID): workgroups of the persistent forward grid. */
+int bh_bn_set_grid_cap(int32_t cap);
 
 /* Stage 2 (one workgroup per layer): mean_c, var_c, r_l, the backward coefficients coef_dev[2 * n_channels] (fp32,
  * 8-byte aligned; d total / d x_l[b,c,hw] = A_c + B_c * x) and total_dev[0] = sum_l weight_l * r_l, added up in layer

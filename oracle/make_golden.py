@@ -394,7 +394,13 @@ def golden_labels():
 
 def golden_dlg():
     """Deep Leakage from Gradients (deepleakage.yaml): joint data+label optimisation with L-BFGS on ConvNet -- the generic
-    torch.optim loop of the joint attacker.  Labels withheld; initial data and labels drawn from the seeded CPU generator."""
+    torch.optim loop of the joint attacker.  Labels withheld; initial data and labels drawn from the seeded CPU generator.
+
+    L-BFGS amplifies rounding differences within its first step (20 closure evaluations, curvature pairs from differences
+    of nearly equal gradients), so besides the free-running history the fixture holds TEACHER-FORCING points: the
+    (candidate, softmaxed label candidate) pairs the reference's closure evaluated at a few of its ~60 objective calls, with
+    the reference objective's value there and its gradient with respect to both (recomputed with the reference's own
+    objective module at exactly those points)."""
     breaching = import_reference()
     from breaching_amd.cases import build_case, parameter_checksum, psnr
 
@@ -402,12 +408,38 @@ def golden_dlg():
     case = build_case("convnet", "CIFAR10", 1, provide_labels=False)
     cfg = _cfg("deepleakage", ["optim.max_iterations=3", "optim.callback=1"])
     attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+    calls = []
+    inner = attacker.objective.forward
+    seen = {}
+
+    def spy(model, gradient_data, candidate, labels):
+        value, task_loss = inner(model, gradient_data, candidate, labels)
+        calls.append((candidate.detach().clone(), labels.detach().clone(), float(value.detach())))
+        seen["model"], seen["gradient_data"] = model, gradient_data
+        return value, task_loss
+
+    attacker.objective.forward = spy
     torch.manual_seed(5)
     rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {})
+    attacker.objective.forward = inner
+    n_loop = len(calls) - 1  # the last call is `_score_trial` on a fresh objective? (no: scoring builds its own module) -- keep all
+    picks = sorted({0, 1, 7, 20, 21, 40, len(calls) - 1} & set(range(len(calls))))
+    forced = dict(x=[], p=[], value=[], gx=[], gp=[], call=[])
+    for k in picks:
+        x, p, value = calls[k]
+        xq, pq = x.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        v, _ = attacker.objective(seen["model"], seen["gradient_data"], xq, pq)
+        gx, gp = torch.autograd.grad(v, [xq, pq])
+        assert abs(float(v) - value) <= 1e-6 * abs(value)
+        for key, item in zip(("x", "p", "value", "gx", "gp", "call"), (x.numpy(), p.numpy(), value, gx.numpy(), gp.numpy(), k)):
+            forced[key].append(item)
     out = dict(history=np.asarray(stats["Trial_0_Val"], dtype=np.float64), opt_value=np.float64(stats["opt_value"]),
                rec=rec["data"].numpy(), labels=rec["labels"].numpy(), seed=np.int64(5),
                psnr=np.float64(psnr(rec["data"], case.true_user_data["data"], case.data_cfg)),
-               model_checksum=np.float64(parameter_checksum(case.model)))
+               model_checksum=np.float64(parameter_checksum(case.model)), n_objective_calls=np.int64(len(calls)),
+               forced_call=np.asarray(forced["call"], dtype=np.int64), forced_x=np.stack(forced["x"]), forced_p=np.stack(forced["p"]),
+               forced_value=np.asarray(forced["value"], dtype=np.float64), forced_gx=np.stack(forced["gx"]),
+               forced_gp=np.stack(forced["gp"]))
     np.savez_compressed(os.path.join(GOLDEN, "attack_dlg.npz"), **out)
 
 

@@ -11,17 +11,17 @@ from breaching_amd.cases import build_case, build_text_case, initial_candidate, 
 parser = argparse.ArgumentParser()
 parser.add_argument("--full", action="store_true")
 parser.add_argument("--only", default=None)
-parser.add_argument("--same-process", action="store_true", help="run all configurations inside this process")
+parser.add_argument("--per-process", action="store_true", help="one process per configuration instead of one process for all")
 args = parser.parse_args()
-if args.only is None and not args.same_process:
-    # One process per configuration, the way attacks are run in practice.  (Observed in round 2: inside ONE process the 4-in-flight
-    # restarts of configs[3], started after the ResNet-50 / DeepInversion run of configs[2], did not finish within a 12-minute
-    # limit, while the same configuration alone takes 207 s -- cause not yet understood, see DESIGN.md open items.)
+if args.only is None and args.per_process:
     import subprocess
 
     for k in "12345":
         subprocess.run([sys.executable, os.path.abspath(__file__), "--only", k] + (["--full"] if args.full else []))
     raise SystemExit(0)
+# Default: ALL configurations in this one process, attack after attack, the way benchmark_breaches.py:60-70 drives an attacker.
+# (Round 2 had to split them: the 4-in-flight restarts of configs[3] ran 3.6x slower after any earlier attack of the process --
+# fixed in round 3, see attacker._run_trial_group and profiles/r3_stall_bisect.jsonl.)
 dev = torch.device("cuda:0")
 setup = dict(device=dev, dtype=torch.float)
 out = {}
@@ -37,7 +37,7 @@ def run(name, case, cfg, x0=None):
     its = sum(len(v) for k, v in stats.items() if k.startswith("Trial_"))
     hist = stats["Trial_0_Val"]
     entry = dict(iterations=its, wall_s=round(dt, 2), iterations_per_s=round(its / dt, 1), first_loss=hist[0], last_loss=hist[-1],
-                 opt_value=stats["opt_value"])
+                 opt_value=stats["opt_value"], execution=sorted(set(stats["execution"]["trials"].values())))
     if case.data_cfg.modality == "vision":
         entry["psnr_db"] = round(psnr(rec["data"], case.true_user_data["data"], case.data_cfg), 3)
     else:

@@ -152,4 +152,10 @@ out["kernelD_resnet50_B8"] = dict(layers=len(acts), elements=total, fwd_items=pl
                                   bwd_us=round(us_b, 1), bwd_GBs=round(2 * total * 4 / us_b / 1e3, 1),
                                   note="one sums launch + one finalize launch forward, one launch backward for all 53 layers "
                                        "(burst of back-to-back launches; 355.6 MB read forward, read + written backward)")
+sweep = {}
+for cap in (512, 1024, 2048, 4096, 1 << 20):
+    lib.bh_bn_set_grid_cap(cap)
+    sweep[str(cap)] = round(burst(d_sums, reps=20, warm=3), 1)
+lib.bh_bn_set_grid_cap(2048)
+out["kernelD_resnet50_B8"]["sums_us_by_grid_cap"] = sweep
 print(json.dumps(out, indent=1))

@@ -139,6 +139,22 @@ def test_two_rank_gloo_selection(tmp_path, num_trials):
     assert r0["value"] == r1["value"]
 
 
+def test_dry_collective_one_rank_gloo():
+    """The one-rank run of the selection collectives (what bench.py and the GPU suite execute with "nccl" on the GPU box),
+    here over gloo on CPU, in a subprocess like there."""
+    import subprocess
+    import sys
+
+    from breaching_amd.trials import parse_dry_collective
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, "-m", "breaching_amd.trials", "--dry-collective", "gloo", "cpu"], cwd=root,
+                          capture_output=True, text=True, timeout=240)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    record = parse_dry_collective(proc.stdout)
+    assert record is not None and record["ok"] and record["backend"] == "gloo" and record["world"] == 1 and record["value"] == 0.25
+
+
 def test_config_overrides_and_attrdict():
     from breaching_amd.config import AttrDict, get_attack_config
 
