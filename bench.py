@@ -39,8 +39,10 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def pmc_traffic_bytes(kernel, sources=None):
     """HBM bytes per launch from the committed PMC passes (profiles/r*_pmc_{fetch,write}_pmc_summary.csv, the newest of
     each): FETCH_SIZE (KB) x 2 -- the gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md section HBM -- plus
-    WRITE_SIZE (KB).  bench.py cannot collect counters itself (separate rocprofv3 --pmc passes do, scripts/gpu_profile.sh);
-    None when the profiles are absent.  `sources` (a list) receives the file names used."""
+    WRITE_SIZE (KB).  bench.py cannot collect counters itself: separate `rocprofv3 --pmc` passes do, one counter per pass,
+    over scripts/pmc_target.py at this workload's list size (round 3: scripts/r3_call6.sh; under the full attack loop
+    rocprofv3's counter collection segfaults inside torch's convolution on this image).  None when the profiles are absent.
+    `sources` (a list) receives the file names used."""
     import csv
     import glob
 
@@ -255,7 +257,8 @@ def main():
         roofline = dict(bound="hbm", kernel="gm_fwd_kernel<cosine>", achieved=round(k["achieved_GBs"], 1), peak=HBM_PEAK_GBS,
                         unit="GB/s", frac=round(k["achieved_GBs"] / HBM_PEAK_GBS, 4),
                         traffic=pmc_traffic_bytes("gm_fwd_kernel", traffic_files),
-                        traffic_source="committed rocprofv3 --pmc passes (not collected in this run): " + ", ".join(traffic_files),
+                        traffic_source="committed rocprofv3 --pmc passes of the same kernel at the same list size (scripts/pmc_target.py; not "
+                                       "collected in this run): " + ", ".join(traffic_files),
                         avg_launch_us=round(k["avg_us"], 2), launches=k["launches"], algorithmic_bytes=fwd_bytes,
                         measured="HIP start/stop events of hipExtLaunchKernelGGL on the launch stream, " +
                                  ("inside the timed region" if timed_with_events else

@@ -47,7 +47,7 @@ class GmChunk(Structure):
 class BnLayer(Structure):
     _fields_ = [("flat_off", c_int64), ("sums_off", c_int64), ("chan_off", c_int32), ("B", c_int32), ("C", c_int32),
                 ("HW", c_int32), ("S", c_int32), ("narrow", c_int32), ("weight", c_float), ("div_unit_mul", c_uint32),
-                ("div_unit_shr", c_uint32), ("div_c_mul", c_uint32), ("div_c_shr", c_uint32), ("reserved", c_int32)]
+                ("div_unit_shr", c_uint32), ("div_c_mul", c_uint32), ("div_c_shr", c_uint32), ("fwd_items", c_int32)]
 
 
 class BnItem(Structure):
@@ -118,6 +118,8 @@ _PROTOTYPES = {
          c_int64, POINTER(BnItem), c_int64],
     ),
     "bh_bn_set_grid_cap": (c_int, [c_int32]),
+    "bh_bn_sums_finalize": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bh_bn_sums": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "bh_bn_finalize": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bh_bn_bwd": (

@@ -852,6 +852,7 @@ class HipOptimizationAttacker:
 
 GRAPH_WARMUP_ITERATIONS = 3
 DEFAULT_TRIALS_IN_FLIGHT = 4
+MAX_TRIALS_IN_FLIGHT = 4
 
 
 class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
@@ -909,14 +910,21 @@ def fast_eval_bn_enabled(cfg):
 
 def trials_in_flight(cfg):
     """How many of a rank's trials run concurrently on separate streams: cfg.impl.trials_in_flight or
-    BREACH_HIP_TRIALS_IN_FLIGHT, default 4 (measured on one MI355X, ResNet-18: 191 / 320 / 403 / 474 iterations/s with
-    1 / 2 / 3 / 4 trials in flight).  1 restores the reference's strictly sequential order; per-trial results do not
-    depend on it."""
+    BREACH_HIP_TRIALS_IN_FLIGHT, default 4, never more than MAX_TRIALS_IN_FLIGHT.  Measured on one MI355X, ResNet-18
+    (profiles/r3_inflight_width.jsonl and round 2): 191 / 320 / 403 / 474 iterations/s with 1 / 2 / 3 / 4 trials in flight,
+    then a collapse -- 215 with 6 and 215 with 8 (GPU_MAX_HW_QUEUES 8 or 16 alike): beyond four concurrently replaying graphs
+    the runtime serialises them.  1 restores the reference's strictly sequential order; per-trial results do not depend on
+    the width."""
     import os
 
     env = os.environ.get("BREACH_HIP_TRIALS_IN_FLIGHT")
     value = int(env) if env is not None else _cfg_get(cfg.impl, "trials_in_flight", DEFAULT_TRIALS_IN_FLIGHT)
-    return max(int(value or DEFAULT_TRIALS_IN_FLIGHT), 1)
+    value = max(int(value or DEFAULT_TRIALS_IN_FLIGHT), 1)
+    if value > MAX_TRIALS_IN_FLIGHT:
+        log.warning(f"trials_in_flight={value} lowered to {MAX_TRIALS_IN_FLIGHT}: more concurrent graph replays than that run "
+                    "slower than four on this platform (measured, see attacker.trials_in_flight).")
+        value = MAX_TRIALS_IN_FLIGHT
+    return value
 
 
 def graph_replay_enabled(cfg):

@@ -173,15 +173,14 @@ __device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, uint32_t mul
   r = n - q * d;
 }
 
-// Forward items (layer, channel, slab) are streamed by a PERSISTENT grid: at most g_bn_grid_cap workgroups, all resident,
-// workgroup w takes items w, w + G, w + 2G, ... (consecutive workgroups work on consecutive items, i.e. on neighbouring
-// memory).  The B planes of a channel are treated as one virtual array of B * HW elements; slab s owns an even share of
+// Forward items (layer, channel, slab) are streamed by min(n_items, g_bn_grid_cap) workgroups; workgroup w takes items
+// w, w + G, w + 2G, ... (consecutive workgroups work on consecutive items, i.e. on neighbouring memory).  Measured on the
+// 355.6 MB of ResNet-50 at B = 8 (profiles/r3_kernel_bench.json): G = 512 / 1024 / 2048 / 4096 / one per item =
+// 111 / 74 / 69 / 64 / 62 us -- a persistent grid does not pay here (items are short, 32 KB, and their descriptor fetch
+// is hidden by the other resident workgroups), so the default is one workgroup per item; the loop stays for the cap.  The B planes of a channel are treated as one virtual array of B * HW elements; slab s owns an even share of
 // it.  Wide layers: the whole workgroup walks the share; narrow layers (B * HW small, late ResNet stages): one wavefront
 // per channel, four channels per workgroup.  Up to eight 16-byte loads are in flight per thread; each thread keeps fp32
-// sums over at most 32 values before spilling into fp64.  The next item's descriptor is fetched while the current one is
-// reduced, and the two LDS reduction buffers alternate, so an item costs one barrier.
-// (Round 2 launched one workgroup per item: 69.9 us for the 355.6 MB of ResNet-50 at B = 8, 0.64 of peak; every
-// workgroup paid its launch plus two dependent descriptor loads before its first bulk load.)
+// sums over at most 32 values before spilling into fp64 (round 2: four loads in flight, 64.5 us in the same burst timing).
 __device__ __forceinline__ void bn_accumulate(const float4& q, float& a0, float& a1) {
   a0 += (q.x + q.y) + (q.z + q.w);
   a1 = fmaf(q.x, q.x, a1);
@@ -208,10 +207,29 @@ __device__ __forceinline__ void bn_load_round(const float4* __restrict__ x4, uin
   d1 += (double)a1;
 }
 
-__global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
-                                                         const bh_bn_item* __restrict__ items, int n_items,
-                                                         double* __restrict__ sums) {
+// Layer finalisation by the workgroup that arrived last at the layer's ticket (fused variant); defined below.
+__device__ void bn_layer_finalize_256(const bh_bn_layer& L, int layer, int n_layers, const double* sums,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float* __restrict__ coef, double* layer_values, float* __restrict__ total,
+                                      unsigned int* tickets, double* lds);
+
+struct BnFused {  // arguments of the fused variant (all null / 0 in the two-launch variant)
+  const float* running_mean;
+  const float* running_var;
+  float* coef;
+  double* layer_values;
+  float* total;
+  unsigned int* tickets;
+  int n_layers;
+};
+
+template <bool FUSED>
+__device__ __forceinline__ void bn_sums_body(const BnPtrs& ptrs, const bh_bn_layer* __restrict__ layers,
+                                             const bh_bn_item* __restrict__ items, int n_items, double* sums,
+                                             const BnFused& fz) {
   __shared__ double lds[2][bh::kWavesPerBlock * 2];
+  __shared__ double fin_lds[bh::kWavesPerBlock * 2 + 2];
+  __shared__ int last_flag;
   const int tid = threadIdx.x;
   int parity = 0;
   int i = blockIdx.x;
@@ -282,6 +300,7 @@ __global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_b
         double* out = sums + 2 * (L.sums_off + (int64_t)c * L.S + it.b);
         out[0] = d0;
         out[1] = d1;
+        if constexpr (FUSED) __threadfence();  // release this wave's pair before the workgroup signs the ticket
       }
     } else {
       double v[2] = {d0, d1};
@@ -290,29 +309,48 @@ __global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_b
         double* out = sums + 2 * (L.sums_off + (int64_t)c * L.S + it.b);
         out[0] = v[0];
         out[1] = v[1];
+        if constexpr (FUSED) __threadfence();
       }
+    }
+    if constexpr (FUSED) {
+      if (narrow) __syncthreads();  // all four waves have released their pairs
+      if (tid == 0) last_flag = atomicAdd(fz.tickets + it.layer, 1u) == (unsigned int)L.fwd_items - 1u;
+      __syncthreads();
+      if (last_flag) {  // every other workgroup of this layer has released its sums: finalise the layer here
+        __threadfence();
+        bn_layer_finalize_256(L, it.layer, fz.n_layers, sums, fz.running_mean, fz.running_var, fz.coef, fz.layer_values, fz.total,
+                              fz.tickets, fin_lds);
+      }
+      __syncthreads();  // last_flag / fin_lds are rewritten by the next item
     }
     it = it_next;
     i = next;
   }
 }
 
-// One workgroup per layer: per-channel mean / biased variance from the slab sums, the two norms of the differences to
-// the running statistics, the layer's weighted statistic and the backward coefficients
-//   d (w * r) / d x[b,c,hw] = A_c + B_c * x[b,c,hw].
-// The workgroup that finishes last adds the layers up in index order (fixed order => reproducible) into total[0].
-constexpr int kBnFinBlock = 1024;  // C up to 2048 channels per layer: two per thread
+__global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
+                                                         const bh_bn_item* __restrict__ items, int n_items,
+                                                         double* __restrict__ sums) {
+  bn_sums_body<false>(ptrs, layers, items, n_items, sums, BnFused{});
+}
 
-__global__ __launch_bounds__(kBnFinBlock) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
-                                                             const double* __restrict__ sums,
-                                                             const float* __restrict__ running_mean,
-                                                             const float* __restrict__ running_var,
-                                                             float* __restrict__ coef, double* layer_values,
-                                                             float* __restrict__ total, unsigned int* counter) {
-  __shared__ double lds[(kBnFinBlock / bh::kWave) * 2];
-  __shared__ double norms[2];
-  __shared__ int finisher;
-  const bh_bn_layer L = layers[blockIdx.x];
+__global__ __launch_bounds__(kBlock) void bn_sums_finalize_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
+                                                                  const bh_bn_item* __restrict__ items, int n_items,
+                                                                  double* sums, BnFused fz) {
+  bn_sums_body<true>(ptrs, layers, items, n_items, sums, fz);
+}
+
+// The per-layer arithmetic of stage 2, shared by both variants: per-channel mean / biased variance from the slab sums, the two
+// norms, the weighted layer value, the backward coefficients.  THREADS threads of one workgroup; `lds`: 2 * waves + 2 doubles.
+// Channels are visited in the same per-thread order and combined in the same fixed tree for a given THREADS, but the tree
+// differs between 1024 (two-launch) and 256 (fused) threads: the two variants agree to fp64 rounding, not bit for bit.
+template <int THREADS>
+__device__ __forceinline__ double bn_layer_statistic(const bh_bn_layer& L, const double* sums,
+                                                     const float* __restrict__ running_mean,
+                                                     const float* __restrict__ running_var, float* __restrict__ coef,
+                                                     double* lds) {
+  constexpr int kWaves = THREADS / bh::kWave;
+  double* norms = lds + kWaves * 2;
   const double n = (double)L.B * (double)L.HW;
   auto channel_stats = [&](int c, double& mean, double& var) {
     double s0 = 0.0, s1 = 0.0;
@@ -326,14 +364,14 @@ __global__ __launch_bounds__(kBnFinBlock) void bn_finalize_kernel(int n_layers, 
     var = var < 0.0 ? 0.0 : var;
   };
   double v[2] = {0.0, 0.0};  // sum (rv - var)^2, sum (rm - mean)^2
-  // the first kBnFinKeep channels of a thread (all of them up to C = 2048) keep their statistics in registers between the
-  // two passes; round 2 re-read and re-summed the slab sums in the second pass
-  constexpr int kBnFinKeep = 2;
-  double kmean[kBnFinKeep], kvar[kBnFinKeep];
-  float krm[kBnFinKeep], krv[kBnFinKeep];
+  // the first kKeep channels of a thread (all of them up to C = 2048) keep their statistics in registers between the two
+  // passes; round 2 re-read and re-summed the slab sums in the second pass
+  constexpr int kKeep = 2048 / THREADS;
+  double kmean[kKeep], kvar[kKeep];
+  float krm[kKeep], krv[kKeep];
 #pragma unroll
-  for (int k = 0; k < kBnFinKeep; ++k) {
-    const int c = threadIdx.x + k * kBnFinBlock;
+  for (int k = 0; k < kKeep; ++k) {
+    const int c = threadIdx.x + k * THREADS;
     kmean[k] = kvar[k] = 0.0;
     krm[k] = krv[k] = 0.f;
     if (c < L.C) {
@@ -345,7 +383,7 @@ __global__ __launch_bounds__(kBnFinBlock) void bn_finalize_kernel(int n_layers, 
       v[1] += dm * dm;
     }
   }
-  for (int c = threadIdx.x + kBnFinKeep * kBnFinBlock; c < L.C; c += kBnFinBlock) {
+  for (int c = threadIdx.x + kKeep * THREADS; c < L.C; c += THREADS) {
     double mean, var;
     channel_stats(c, mean, var);
     const double dvv = (double)running_var[L.chan_off + c] - var, dm = (double)running_mean[L.chan_off + c] - mean;
@@ -365,28 +403,58 @@ __global__ __launch_bounds__(kBnFinBlock) void bn_finalize_kernel(int n_layers, 
     reinterpret_cast<float2*>(coef)[L.chan_off + c] = make_float2((float)(w * (pm - 2.0 * pv * mean) / n), (float)(w * 2.0 * pv / n));
   };
 #pragma unroll
-  for (int k = 0; k < kBnFinKeep; ++k) {
-    const int c = threadIdx.x + k * kBnFinBlock;
+  for (int k = 0; k < kKeep; ++k) {
+    const int c = threadIdx.x + k * THREADS;
     if (c < L.C) write_coef(c, kmean[k], kvar[k], (double)krm[k], (double)krv[k]);
   }
-  for (int c = threadIdx.x + kBnFinKeep * kBnFinBlock; c < L.C; c += kBnFinBlock) {
+  for (int c = threadIdx.x + kKeep * THREADS; c < L.C; c += THREADS) {
     double mean, var;
     channel_stats(c, mean, var);
     write_coef(c, mean, var, (double)running_mean[L.chan_off + c], (double)running_var[L.chan_off + c]);
   }
-  if (threadIdx.x == 0) {
-    layer_values[blockIdx.x] = w * (nv + nm);
-    __threadfence();
-    finisher = atomicAdd(counter, 1u) == (unsigned int)n_layers - 1u;
-  }
-  __syncthreads();
-  if (!finisher || threadIdx.x != 0) return;
+  return w * (nv + nm);
+}
+
+// Thread 0 of the workgroup that finalised a layer: publish the layer value, sign the model-wide ticket; the last layer to
+// arrive adds the layers up in index order (fixed order => reproducible) and re-zeroes `n_reset` ticket words.
+__device__ __forceinline__ void bn_publish_layer(int layer, int n_layers, double value, double* layer_values,
+                                                 float* __restrict__ total, unsigned int* model_ticket,
+                                                 unsigned int* reset, int n_reset) {
+  layer_values[layer] = value;
+  __threadfence();
+  if (atomicAdd(model_ticket, 1u) != (unsigned int)n_layers - 1u) return;
   __threadfence();
   // reference order (regularizers.py:222-227): fp32 adds layer by layer; here fp64, rounded once
   double sum = 0.0;
   for (int l = 0; l < n_layers; ++l) sum += layer_values[l];
   total[0] = (float)sum;
-  *counter = 0u;
+  for (int k = 0; k < n_reset; ++k) reset[k] = 0u;
+}
+
+__device__ void bn_layer_finalize_256(const bh_bn_layer& L, int layer, int n_layers, const double* sums,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float* __restrict__ coef, double* layer_values, float* __restrict__ total,
+                                      unsigned int* tickets, double* lds) {
+  const double value = bn_layer_statistic<kBlock>(L, sums, running_mean, running_var, coef, lds);
+  if (threadIdx.x == 0)
+    bn_publish_layer(layer, n_layers, value, layer_values, total, tickets + n_layers, tickets, n_layers + 1);
+}
+
+
+// Two-launch variant, stage 2: one workgroup per layer (see bn_layer_statistic), the workgroup that finishes last adds the
+// layers up into total[0].
+constexpr int kBnFinBlock = 1024;  // C up to 2048 channels per layer: two per thread
+
+__global__ __launch_bounds__(kBnFinBlock) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
+                                                             const double* __restrict__ sums,
+                                                             const float* __restrict__ running_mean,
+                                                             const float* __restrict__ running_var,
+                                                             float* __restrict__ coef, double* layer_values,
+                                                             float* __restrict__ total, unsigned int* counter) {
+  __shared__ double lds[(kBnFinBlock / bh::kWave) * 2 + 2];
+  const bh_bn_layer L = layers[blockIdx.x];
+  const double value = bn_layer_statistic<kBnFinBlock>(L, sums, running_mean, running_var, coef, lds);
+  if (threadIdx.x == 0) bn_publish_layer(blockIdx.x, n_layers, value, layer_values, total, counter, counter, 1);
 }
 
 // One workgroup per backward item: BH_BN_TILE consecutive elements of one layer (16-byte vectors when HW % 4 == 0).
@@ -452,7 +520,7 @@ void find_divisor(uint32_t d, uint32_t& mul, uint32_t& shr) {
   shr = p - 32u;
 }
 
-int g_bn_grid_cap = BH_BN_DEFAULT_GRID;        // persistent forward grid: workgroups resident at once (8 per CU)
+int g_bn_grid_cap = BH_BN_DEFAULT_GRID;        // cap of the forward grid (default: none)
 
 constexpr int64_t kBnTargetPerGroup = 8192;  // elements one forward workgroup should see, roughly
 constexpr int64_t kBnNarrowLimit = 2048;     // B * HW below this: one wavefront per channel
@@ -558,6 +626,7 @@ int bh_bn_plan_build(int32_t n_layers, const int32_t* B, const int32_t* C, const
     L.S = g.S;
     L.narrow = g.narrow;
     L.weight = weights ? weights[l] : 1.f;
+    L.fwd_items = (int32_t)g.fwd_items;
     const bool vec = (HW[l] & 3) == 0;
     find_divisor((uint32_t)(vec ? HW[l] / 4 : HW[l]), L.div_unit_mul, L.div_unit_shr);
     find_divisor((uint32_t)C[l], L.div_c_mul, L.div_c_shr);
@@ -603,6 +672,26 @@ int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_ho
   const int64_t grid = n_fwd_items < g_bn_grid_cap ? n_fwd_items : (int64_t)g_bn_grid_cap;
   hipLaunchKernelGGL(bn_sums_kernel, dim3((unsigned int)grid), dim3(kBlock), 0, bh::as_stream(stream), ptrs, layers_dev,
                      fwd_items_dev, (int)n_fwd_items, sums_dev);
+  return bh::launch_status();
+}
+
+int bh_bn_sums_finalize(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
+                        const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, const float* running_mean,
+                        const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
+                        void* tickets_dev, void* stream) {
+  if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || x_ptrs == nullptr || hw_host == nullptr || layers_dev == nullptr ||
+      fwd_items_dev == nullptr || n_fwd_items <= 0 || n_fwd_items > INT32_MAX || sums_dev == nullptr ||
+      running_mean == nullptr || running_var == nullptr || coef_dev == nullptr || layer_values_dev == nullptr ||
+      total_dev == nullptr || tickets_dev == nullptr)
+    return BH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(coef_dev) & 7u) != 0) return BH_EINVAL;  // written / read back as float2
+  BnPtrs ptrs;
+  if (!fill_bn_ptrs(ptrs, x_ptrs, n_layers, hw_host)) return BH_EINVAL;
+  const BnFused fz{running_mean, running_var, coef_dev, layer_values_dev, total_dev, static_cast<unsigned int*>(tickets_dev),
+                   n_layers};
+  const int64_t grid = n_fwd_items < g_bn_grid_cap ? n_fwd_items : (int64_t)g_bn_grid_cap;
+  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3((unsigned int)grid), dim3(kBlock), 0, bh::as_stream(stream), ptrs,
+                     layers_dev, fwd_items_dev, (int)n_fwd_items, sums_dev, fz);
   return bh::launch_status();
 }
 

@@ -621,7 +621,9 @@ class HipPearlmutterEuclidean(HipGradientLoss):
         buffers = dict(model.named_buffers())
         task_loss = self.loss_fn(model(candidate), labels)
         *gradients, dLdx = torch.autograd.grad(task_loss, (*params, candidate), create_graph=False)
-        if self.level_gradients:  # :336-339
+        if self.level_gradients and self.implementation in ("forward", "backward"):
+            # :345-348, :373-376 -- the reference levels the gradients only in its forward / backward variants; its central
+            # and upwind variants (:394-452) ignore the flag, and so do these
             grad_norm = torch.stack([g.pow(2).sum() for g in gradients]).sum().sqrt()
             torch._foreach_div_(gradients, max(grad_norm, self.fudge_factor))
         plan = self._plan_for(gradients, gradient_data)

@@ -167,6 +167,18 @@ class BnStatPlan:
         return (c_void_p * self.n_layers)(*[x.data_ptr() for x in xs])
 
 
+def bn_fused_forward():
+    """One launch (sums + per-layer finalize by the last arriver, `bh_bn_sums_finalize`) or two (`bh_bn_sums`, `bh_bn_finalize`)
+    for the forward stage of kernel D: BREACH_HIP_BN_FUSED=1 / 0, default set from the round-3 measurement
+    (profiles/r3_kernel_bench.json)."""
+    import os
+
+    return os.environ.get("BREACH_HIP_BN_FUSED", BN_FUSED_DEFAULT) != "0"
+
+
+BN_FUSED_DEFAULT = "0"
+
+
 class _BnStatFunction(torch.autograd.Function):
     """total(x_0 .. x_{L-1}) = sum_l weight_l * (||running_var_l - var_c(x_l)||_2 + ||running_mean_l - mean_c(x_l)||_2)
     as ONE autograd node over all BatchNorm inputs: three launches forward+backward for the whole model."""
@@ -190,13 +202,19 @@ class _BnStatFunction(torch.autograd.Function):
             coef = torch.empty(2 * plan.n_channels, dtype=torch.float32, device=dev)
             total = torch.empty(1, dtype=torch.float32, device=dev)
             if ticket is None:
-                ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+                ticket = torch.zeros(plan.n_layers + 1, dtype=torch.int32, device=dev)
             ptrs = plan.pointers(prepared)
-            _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
-                                      plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
-            _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
-                                          _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
-                                          _lib.ptr(ticket), stream), "bh_bn_finalize")
+            if bn_fused_forward():
+                _lib.check(lib.bh_bn_sums_finalize(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
+                                                   plan.n_fwd, _lib.ptr(sums), _lib.ptr(plan.running_mean), _lib.ptr(plan.running_var),
+                                                   _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total), _lib.ptr(ticket), stream),
+                           "bh_bn_sums_finalize")
+            else:
+                _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
+                                          plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
+                _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
+                                              _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
+                                              _lib.ptr(ticket), stream), "bh_bn_finalize")
         ctx.plan = plan
         ctx.save_for_backward(coef, *prepared)
         ctx.in_shapes = [x.shape for x in xs]
@@ -304,7 +322,8 @@ class HipDeepInversion(torch.nn.Module):
             if self.ticket_scope is not None:
                 ticket = self.ticket_scope.get(("bn", idx))
                 if ticket is None:
-                    ticket = self.ticket_scope[("bn", idx)] = torch.zeros(1, dtype=torch.int32, device=plan.device)
+                    # one word per layer + one for the model (the fused forward signs per layer; the two-launch one uses word 0)
+                    ticket = self.ticket_scope[("bn", idx)] = torch.zeros(plan.n_layers + 1, dtype=torch.int32, device=plan.device)
             total = total + _BnStatFunction.apply(plan, ticket, *xs)
         return total
 

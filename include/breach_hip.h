@@ -184,7 +184,9 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
  * host array of device pointers (kernel arguments, at most BH_BN_MAX_LAYERS), their geometry in a device table. */
 #define BH_BN_MAX_LAYERS 448
 #define BH_BN_TILE 4096 /* elements per backward work item */
-#define BH_BN_DEFAULT_GRID 2048 /* persistent forward grid: workgroups resident at once (8 per CU on 256 CUs) */
+#define BH_BN_DEFAULT_GRID (1 << 20) /* cap of the forward grid; measured round 3 (profiles/r3_kernel_bench.json, 355.6 MB):
+                                       * 512 / 1024 / 2048 / 4096 / uncapped workgroups = 111 / 74 / 69 / 64 / 62 us -- unlike
+                                       * kernel A the item stream wants every workgroup it can get, so no cap by default */
 
 typedef struct bh_bn_layer { /* 64 bytes, device resident, built once per attack by bh_bn_plan_build */
   int64_t flat_off;      /* element offset of the layer inside the packed gradient buffer (multiple of 4) */
@@ -196,7 +198,7 @@ typedef struct bh_bn_layer { /* 64 bytes, device resident, built once per attack
   float weight;          /* weight_l */
   uint32_t div_unit_mul, div_unit_shr; /* fast division by HW/4 (HW % 4 == 0) or HW */
   uint32_t div_c_mul, div_c_shr;       /* fast division by C */
-  int32_t reserved;
+  int32_t fwd_items;     /* forward items (workgroups of stage 1) of this layer: the arrival count of its ticket */
 } bh_bn_layer;
 
 typedef struct bh_bn_item { /* 16 bytes: forward (layer, channel [first of 4 when narrow], slab, -); */
@@ -211,8 +213,8 @@ int bh_bn_plan_build(int32_t n_layers, const int32_t* B, const int32_t* C, const
                      bh_bn_layer* layers, bh_bn_item* fwd_items, int64_t n_fwd_items, bh_bn_item* bwd_items,
                      int64_t n_bwd_items);
 
-/* Stage 1: per-channel sum and sum of squares of every layer -- a persistent grid of at most BH_BN_DEFAULT_GRID workgroups
- * (bh_bn_set_grid_cap) streams the forward items -- into sums_dev[2 * n_sum_pairs] doubles (overwritten).  `x_ptrs` / `hw_host`: HOST arrays (device pointers, HW per layer).
+/* Stage 1: per-channel sum and sum of squares of every layer -- min(n_fwd_items, cap) workgroups stream the forward items
+ * (cap = BH_BN_DEFAULT_GRID unless bh_bn_set_grid_cap changed it) -- into sums_dev[2 * n_sum_pairs] doubles (overwritten).  `x_ptrs` / `hw_host`: HOST arrays (device pointers, HW per layer).
  * reference: deepinversion.py:93-96 (mean / biased var of the BN input). */
 int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
                const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, void* stream);
@@ -228,6 +230,16 @@ int bh_bn_set_grid_cap(int32_t cap);
 int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double* sums_dev, const float* running_mean,
                    const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
                    void* counter_dev, void* stream);
+
+/* Stages 1 + 2 in ONE launch: every stage-1 workgroup signs its layer's ticket after writing its sums; the workgroup that
+ * arrives last at a layer finalises that layer (as stage 2 does), and the last layer to finish adds the layers up in index
+ * order.  `tickets_dev`: n_layers + 1 zeroed uint32 words (re-zeroed by the kernel).  Same per-layer arithmetic as
+ * bh_bn_sums + bh_bn_finalize in fixed (run-to-run reproducible) orders; the layer norms are combined by 256 instead of
+ * 1024 threads, so the two variants agree to fp64 rounding of the norms (identical after the cast to fp32 in practice). */
+int bh_bn_sums_finalize(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
+                        const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, const float* running_mean,
+                        const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
+                        void* tickets_dev, void* stream);
 
 /* Backward of all layers in one launch: grad_flat[flat_off_l + i] = gout * (A_c + B_c * x_l[i]); gout read from
  * *gout_dev (NULL = 1).  grad_flat (16-byte aligned, flat_elems floats) is overwritten. */

@@ -11,6 +11,7 @@ from breaching_amd.cases import build_case, build_text_case, initial_candidate, 
 parser = argparse.ArgumentParser()
 parser.add_argument("--full", action="store_true")
 parser.add_argument("--only", default=None)
+parser.add_argument("--its", type=int, default=200, help="iterations of the short configurations (configs[2], configs[4])")
 parser.add_argument("--per-process", action="store_true", help="one process per configuration instead of one process for all")
 args = parser.parse_args()
 if args.only is None and args.per_process:
@@ -57,8 +58,8 @@ if args.only in (None, "2"):
         breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={its}"]), initial_candidate(case.data_cfg, 1))
 if args.only in (None, "3"):
     case = build_case("resnet50", "ImageNet", 8, device=dev, gradient_device=dev, provide_buffers=True)
-    run("configs[2] ResNet-50 ImageNet batch 8 see-through-gradients (+DeepInversion), 200 its", case,
-        breaching_amd.get_attack_config("seethroughgradients", ["optim.max_iterations=200", "optim.callback=100"]), initial_candidate(case.data_cfg, 8))
+    run(f"configs[2] ResNet-50 ImageNet batch 8 see-through-gradients (+DeepInversion), {args.its} its", case,
+        breaching_amd.get_attack_config("seethroughgradients", [f"optim.max_iterations={args.its}", "optim.callback=100"]), initial_candidate(case.data_cfg, 8))
 if args.only in (None, "4"):
     case = build_case("resnet18", "ImageNet", 1, device=dev, gradient_device=dev)
     its = 24000 if args.full else 500
@@ -66,6 +67,6 @@ if args.only in (None, "4"):
         breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={its}", "restarts.num_trials=4"]))
 if args.only in (None, "5"):
     case = build_text_case(device=dev, full_size=True, seq_len=32)
-    run("configs[4] BERT-base seq 32 TAG joint attack, 200 its", case,
-        breaching_amd.get_attack_config("tag", ["optim.max_iterations=200", "optim.callback=100"]))
+    run(f"configs[4] BERT-base seq 32 TAG joint attack, {args.its} its", case,
+        breaching_amd.get_attack_config("tag", [f"optim.max_iterations={args.its}", "optim.callback=100"]))
 print(json.dumps(out, indent=1))

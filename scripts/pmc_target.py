@@ -1,0 +1,66 @@
+"""Small, bounded target for rocprofv3 --pmc passes: kernel A forward / finalize / backward on a
+synthetic gradient list of one BASELINE size, and kernel D on the 53 BatchNorm inputs of ResNet-50 at B = 8.  A handful of
+launches each, nothing else on the GPU -- the full bench under --pmc WRITE_SIZE died inside rocprofv3 twice in round 2.
+
+    rocprofv3 --pmc WRITE_SIZE -- python scripts/pmc_target.py --size resnet18|resnet50|bert|bn [--reps 6]
+"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from breaching_amd import _lib
+from breaching_amd.cases import ResNet, build_text_case
+from breaching_amd.gm import GradientMatchPlan
+
+p = argparse.ArgumentParser()
+p.add_argument("--size", default="resnet18")
+p.add_argument("--reps", type=int, default=6)
+args = p.parse_args()
+dev = torch.device("cuda:0")
+lib = _lib.load()
+gen = torch.Generator().manual_seed(0)
+if args.size == "bn":
+    from breaching_amd.priors import BnStatPlan
+
+    acts = []
+    model = ResNet(50, 1000).to(dev).eval()
+    hooks = [m.register_forward_hook(lambda m, i, o: acts.append(i[0].detach().contiguous())) for m in model.modules()
+             if isinstance(m, torch.nn.BatchNorm2d)]
+    with torch.no_grad():
+        model(torch.randn(8, 3, 224, 224, device=dev))
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    plan = BnStatPlan([a.shape for a in acts], [m.running_mean for m in bns], [m.running_var for m in bns], [1.0] * len(acts), dev)
+    sums = torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=dev)
+    layer_values = torch.empty(plan.n_layers, dtype=torch.float64, device=dev)
+    coef = torch.empty(2 * plan.n_channels, device=dev)
+    total, ticket = torch.empty(1, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
+    grad_flat = torch.empty(plan.flat_elems, device=dev)
+    ptrs = plan.pointers(acts)
+    st = _lib.current_stream_handle(dev)
+    for _ in range(args.reps):
+        _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev), plan.n_fwd,
+                                  _lib.ptr(sums), st), "sums")
+        _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
+                                      _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
+                                      _lib.ptr(ticket), st), "finalize")
+        _lib.check(lib.bh_bn_bwd(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.bwd_dev), plan.n_bwd,
+                                 _lib.ptr(coef), None, _lib.ptr(grad_flat), st), "bwd")
+    torch.cuda.synchronize()
+    print("bn", sum(a.numel() for a in acts), "elements", float(total))
+else:
+    if args.size == "bert":
+        case = build_text_case(device=dev, full_size=True, seq_len=32)
+        shapes = [tuple(g.shape) for g in case.shared_data[0]["gradients"]][1:]  # word-embedding gradient popped
+        kind_name = "tag-euclidean"
+    else:
+        shapes = [tuple(q.shape) for q in ResNet(18 if args.size == "resnet18" else 50, 1000).parameters()]
+        kind_name = "cosine-similarity" if args.size == "resnet18" else "euclidean"
+    data = [torch.randn(s, generator=gen).to(dev) for s in shapes]
+    rec = [torch.randn(s, generator=gen).to(dev) for s in shapes]
+    plan = GradientMatchPlan(data)
+    kind = _lib.GM_KINDS[kind_name]
+    weights = torch.linspace(1, 0.1, len(shapes), device=dev) if kind_name == "tag-euclidean" else None
+    for _ in range(args.reps):
+        stats = plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights)
+        plan.backward(kind, rec, stats, None, weights)
+    torch.cuda.synchronize()
+    print(args.size, plan.total_elements, "elements", plan.n_rows, "rows", float(stats[0]))

@@ -191,8 +191,15 @@ def test_tv_norm_matches_c_oracle(shape, opp, kernels_oracle, hip_lib):
     _assert_grads([grad.cpu().numpy()], [want_g], rtol=1e-6)
 
 
+@pytest.fixture(params=["two-launch", "fused"])
+def bn_forward_variant(request, monkeypatch):
+    """Kernel D's forward stage both ways: bh_bn_sums + bh_bn_finalize, and the single launch bh_bn_sums_finalize."""
+    monkeypatch.setenv("BREACH_HIP_BN_FUSED", "1" if request.param == "fused" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib):
+def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib, bn_forward_variant):
     from breaching_amd.priors import bn_statistic
 
     gold = np.load(os.path.join(golden_dir, "kernels.npz"))
@@ -207,7 +214,7 @@ def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib):
 
 
 @pytest.mark.parametrize("shape", [(8, 64, 112, 112), (8, 2048, 7, 7), (2, 256, 14, 14), (1, 3, 5, 5)])
-def test_bnstat_matches_c_oracle(shape, kernels_oracle, hip_lib):
+def test_bnstat_matches_c_oracle(shape, kernels_oracle, hip_lib, bn_forward_variant):
     from breaching_amd.priors import bn_statistic
     from oracle import kernels_ref
 
@@ -316,7 +323,7 @@ def test_candidate_step_best_copy_is_post_step_candidate(kernels_oracle, hip_lib
     np.testing.assert_allclose(r["best"], r["best_o"], rtol=2e-5, atol=2e-6)
 
 
-def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_lib):
+def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_lib, bn_forward_variant):
     """Kernel D over a whole model's BatchNorm inputs at once: wide (whole workgroup per channel slab), narrow (one wavefront
     per channel), vectorised and scalar (H*W % 4 != 0) layers mixed; total = sum_l w_l * r_l and every layer's gradient."""
     from breaching_amd.priors import BnStatPlan, _BnStatFunction
@@ -331,8 +338,8 @@ def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_li
     xs = [torch.tensor(x, device=_dev(), requires_grad=True) for x in xs_np]
     plan = BnStatPlan([x.shape for x in xs], [torch.tensor(m, device=_dev()) for m in rms],
                       [torch.tensor(v, device=_dev()) for v in rvs], weights, _dev())
-    ticket = torch.zeros(1, dtype=torch.int32, device=_dev())
-    for _ in range(2):  # the ticket word is re-zeroed by the kernel: the second call must work like the first
+    ticket = torch.zeros(plan.n_layers + 1, dtype=torch.int32, device=_dev())
+    for _ in range(3):  # the ticket words are re-zeroed by the kernel: later calls must work like the first
         total = _BnStatFunction.apply(plan, ticket, *xs)
         grads = torch.autograd.grad(total * 0.7, xs)
         want_total, want_grads = 0.0, []
@@ -343,7 +350,7 @@ def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_li
         assert abs(total.item() - want_total) <= 2e-6 * abs(want_total)
         for g, wg in zip(grads, want_grads):
             _assert_grads([g.cpu().numpy()], [wg], rtol=1e-5)
-    assert int(ticket.item()) == 0
+    assert int(ticket.abs().sum().item()) == 0
 
 
 def test_gm_forward_rows_cap_only_changes_summation_order(hip_lib):
