@@ -117,9 +117,10 @@ _PROTOTYPES = {
         [c_int32, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), POINTER(c_float), POINTER(BnLayer), POINTER(BnItem),
          c_int64, POINTER(BnItem), c_int64],
     ),
+    "bh_bn_bwd_accumulate": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bh_bn_set_grid_cap": (c_int, [c_int32]),
-    "bh_bn_sums_finalize": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
-                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bh_bn_set_finalize_block": (c_int, [c_int32]),
+    "bh_bn_set_load_depth": (c_int, [c_int32]),
     "bh_bn_sums": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "bh_bn_finalize": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bh_bn_bwd": (

@@ -207,29 +207,15 @@ __device__ __forceinline__ void bn_load_round(const float4* __restrict__ x4, uin
   d1 += (double)a1;
 }
 
-// Layer finalisation by the workgroup that arrived last at the layer's ticket (fused variant); defined below.
-__device__ void bn_layer_finalize_256(const bh_bn_layer& L, int layer, int n_layers, const double* sums,
-                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
-                                      float* __restrict__ coef, double* layer_values, float* __restrict__ total,
-                                      unsigned int* tickets, double* lds);
-
-struct BnFused {  // arguments of the fused variant (all null / 0 in the two-launch variant)
-  const float* running_mean;
-  const float* running_var;
-  float* coef;
-  double* layer_values;
-  float* total;
-  unsigned int* tickets;
-  int n_layers;
-};
-
-template <bool FUSED>
-__device__ __forceinline__ void bn_sums_body(const BnPtrs& ptrs, const bh_bn_layer* __restrict__ layers,
-                                             const bh_bn_item* __restrict__ items, int n_items, double* sums,
-                                             const BnFused& fz) {
+// Measured and rejected in round 3 (commit 32ae57f, profiles/r3_kernel_bench_with_fused_bn_forward.json): finalising each layer
+// inside this launch through a per-layer last-arriver ticket.  Every one of the 14 400 workgroups then needs an agent-scope
+// release fence + ticket atomic: 1157 us instead of 63.5 + 12.3 us for the two launches (~80 ns per workgroup, serialised) --
+// the same cost kernel A's fused epilogue showed in round 2.  Results were identical bit for bit; the two launches stay.
+template <int DEPTH>  // 16-byte loads in flight per thread in the main loop: 8 (default) or 4
+__global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
+                                                         const bh_bn_item* __restrict__ items, int n_items,
+                                                         double* __restrict__ sums) {
   __shared__ double lds[2][bh::kWavesPerBlock * 2];
-  __shared__ double fin_lds[bh::kWavesPerBlock * 2 + 2];
-  __shared__ int last_flag;
   const int tid = threadIdx.x;
   int parity = 0;
   int i = blockIdx.x;
@@ -257,11 +243,12 @@ __device__ __forceinline__ void bn_sums_body(const BnPtrs& ptrs, const bh_bn_lay
         const uint32_t cstride = (uint32_t)L.C * unit;  // float4s between consecutive planes of one channel
         const uint32_t cbase = (uint32_t)c * unit;
         uint32_t v = v0 + (uint32_t)lane;
-        for (; v + 7u * lanes < v1; v += 8u * lanes)
-          bn_load_round<8>(x4, v, lanes, unit, cstride, cbase, L.div_unit_mul, L.div_unit_shr, d0, d1);
-        if (v + 3u * lanes < v1) {
+        if constexpr (DEPTH == 8) {
+          for (; v + 7u * lanes < v1; v += 8u * lanes)
+            bn_load_round<8>(x4, v, lanes, unit, cstride, cbase, L.div_unit_mul, L.div_unit_shr, d0, d1);
+        }
+        for (; v + 3u * lanes < v1; v += 4u * lanes) {  // at most once when DEPTH == 8
           bn_load_round<4>(x4, v, lanes, unit, cstride, cbase, L.div_unit_mul, L.div_unit_shr, d0, d1);
-          v += 4u * lanes;
         }
         float a0 = 0.f, a1 = 0.f;
         for (; v < v1; v += lanes) {
@@ -300,7 +287,6 @@ __device__ __forceinline__ void bn_sums_body(const BnPtrs& ptrs, const bh_bn_lay
         double* out = sums + 2 * (L.sums_off + (int64_t)c * L.S + it.b);
         out[0] = d0;
         out[1] = d1;
-        if constexpr (FUSED) __threadfence();  // release this wave's pair before the workgroup signs the ticket
       }
     } else {
       double v[2] = {d0, d1};
@@ -309,41 +295,15 @@ __device__ __forceinline__ void bn_sums_body(const BnPtrs& ptrs, const bh_bn_lay
         double* out = sums + 2 * (L.sums_off + (int64_t)c * L.S + it.b);
         out[0] = v[0];
         out[1] = v[1];
-        if constexpr (FUSED) __threadfence();
       }
-    }
-    if constexpr (FUSED) {
-      if (narrow) __syncthreads();  // all four waves have released their pairs
-      if (tid == 0) last_flag = atomicAdd(fz.tickets + it.layer, 1u) == (unsigned int)L.fwd_items - 1u;
-      __syncthreads();
-      if (last_flag) {  // every other workgroup of this layer has released its sums: finalise the layer here
-        __threadfence();
-        bn_layer_finalize_256(L, it.layer, fz.n_layers, sums, fz.running_mean, fz.running_var, fz.coef, fz.layer_values, fz.total,
-                              fz.tickets, fin_lds);
-      }
-      __syncthreads();  // last_flag / fin_lds are rewritten by the next item
     }
     it = it_next;
     i = next;
   }
 }
 
-__global__ __launch_bounds__(kBlock) void bn_sums_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
-                                                         const bh_bn_item* __restrict__ items, int n_items,
-                                                         double* __restrict__ sums) {
-  bn_sums_body<false>(ptrs, layers, items, n_items, sums, BnFused{});
-}
-
-__global__ __launch_bounds__(kBlock) void bn_sums_finalize_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
-                                                                  const bh_bn_item* __restrict__ items, int n_items,
-                                                                  double* sums, BnFused fz) {
-  bn_sums_body<true>(ptrs, layers, items, n_items, sums, fz);
-}
-
-// The per-layer arithmetic of stage 2, shared by both variants: per-channel mean / biased variance from the slab sums, the two
-// norms, the weighted layer value, the backward coefficients.  THREADS threads of one workgroup; `lds`: 2 * waves + 2 doubles.
-// Channels are visited in the same per-thread order and combined in the same fixed tree for a given THREADS, but the tree
-// differs between 1024 (two-launch) and 256 (fused) threads: the two variants agree to fp64 rounding, not bit for bit.
+// The per-layer arithmetic of stage 2: per-channel mean / biased variance from the slab sums, the two norms, the weighted
+// layer value, the backward coefficients.  THREADS threads of one workgroup; `lds`: 2 * waves + 2 doubles.
 template <int THREADS>
 __device__ __forceinline__ double bn_layer_statistic(const bh_bn_layer& L, const double* sums,
                                                      const float* __restrict__ running_mean,
@@ -431,31 +391,23 @@ __device__ __forceinline__ void bn_publish_layer(int layer, int n_layers, double
   for (int k = 0; k < n_reset; ++k) reset[k] = 0u;
 }
 
-__device__ void bn_layer_finalize_256(const bh_bn_layer& L, int layer, int n_layers, const double* sums,
-                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
-                                      float* __restrict__ coef, double* layer_values, float* __restrict__ total,
-                                      unsigned int* tickets, double* lds) {
-  const double value = bn_layer_statistic<kBlock>(L, sums, running_mean, running_var, coef, lds);
-  if (threadIdx.x == 0)
-    bn_publish_layer(layer, n_layers, value, layer_values, total, tickets + n_layers, tickets, n_layers + 1);
-}
-
-
-// Two-launch variant, stage 2: one workgroup per layer (see bn_layer_statistic), the workgroup that finishes last adds the
-// layers up into total[0].
-constexpr int kBnFinBlock = 1024;  // C up to 2048 channels per layer: two per thread
-
-__global__ __launch_bounds__(kBnFinBlock) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
-                                                             const double* __restrict__ sums,
-                                                             const float* __restrict__ running_mean,
-                                                             const float* __restrict__ running_var,
-                                                             float* __restrict__ coef, double* layer_values,
-                                                             float* __restrict__ total, unsigned int* counter) {
-  __shared__ double lds[(kBnFinBlock / bh::kWave) * 2 + 2];
+// Stage 2: one workgroup per layer (see bn_layer_statistic), the workgroup that finishes last adds the layers up into
+// total[0].  THREADS: 256 / 512 / 1024 (bh_bn_set_finalize_block; the statistics of up to 2048 channels stay in registers).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
+                                                         const double* __restrict__ sums,
+                                                         const float* __restrict__ running_mean,
+                                                         const float* __restrict__ running_var, float* __restrict__ coef,
+                                                         double* layer_values, float* __restrict__ total,
+                                                         unsigned int* counter) {
+  __shared__ double lds[(THREADS / bh::kWave) * 2 + 2];
   const bh_bn_layer L = layers[blockIdx.x];
-  const double value = bn_layer_statistic<kBnFinBlock>(L, sums, running_mean, running_var, coef, lds);
+  const double value = bn_layer_statistic<THREADS>(L, sums, running_mean, running_var, coef, lds);
   if (threadIdx.x == 0) bn_publish_layer(blockIdx.x, n_layers, value, layer_values, total, counter, counter, 1);
 }
+
+int g_bn_fin_block = BH_BN_DEFAULT_FINALIZE_BLOCK;
+int g_bn_load_depth = 8;
 
 // One workgroup per backward item: BH_BN_TILE consecutive elements of one layer (16-byte vectors when HW % 4 == 0).
 __global__ __launch_bounds__(kBlock) void bn_bwd_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
@@ -502,6 +454,59 @@ __global__ __launch_bounds__(kBlock) void bn_bwd_kernel(BnPtrs ptrs, const bh_bn
       fast_divmod(plane, (uint32_t)L.C, L.div_c_mul, L.div_c_shr, bidx, c);
       const float2 kk = ab[c];
       o[begin + i] = fmaf(g * kk.y, x[begin + i], g * kk.x);
+    }
+  }
+}
+
+// Backward of ONE layer fused with the accumulation into the activation gradient (the read-modify-write autograd would
+// otherwise do with one ATen `add` per layer): out[i] = gin[i] + g * (A_c + B_c * x[i]); gin may be null (no other
+// contribution reached this activation).  Same items / index arithmetic as bn_bwd_kernel, addresses local to the layer.
+__global__ __launch_bounds__(kBlock) void bn_bwd_acc_kernel(const float* __restrict__ x, const float* __restrict__ gin,
+                                                            float* __restrict__ o, const bh_bn_layer* __restrict__ layers,
+                                                            const bh_bn_item* __restrict__ items,
+                                                            const float* __restrict__ coef, const float* __restrict__ gout) {
+  const bh_bn_item it = items[blockIdx.x];
+  const bh_bn_layer L = layers[it.layer];
+  const float g = gout ? gout[0] : 1.f;
+  const float2* __restrict__ ab = reinterpret_cast<const float2*>(coef) + L.chan_off;
+  const uint32_t begin = (uint32_t)it.a, count = (uint32_t)it.b;  // in float4s when vectorised, floats otherwise
+  if ((L.HW & 3) == 0) {
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gin);
+    float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
+    const uint32_t unit = (uint32_t)(L.HW >> 2);
+    float4 q[4], acc[4];
+    float2 k[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = threadIdx.x + u * kBlock;
+      if (i < count) {
+        uint32_t plane, j, bidx, c;
+        fast_divmod(begin + i, unit, L.div_unit_mul, L.div_unit_shr, plane, j);
+        fast_divmod(plane, (uint32_t)L.C, L.div_c_mul, L.div_c_shr, bidx, c);
+        q[u] = x4[begin + i];
+        acc[u] = gin ? g4[begin + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        k[u] = ab[c];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t i = threadIdx.x + u * kBlock;
+      if (i < count) {
+        const float a = g * k[u].x, b = g * k[u].y;
+        // the statistic's term is rounded exactly as bn_bwd_kernel rounds it, then added like autograd's `add` would
+        o4[begin + i] = make_float4(acc[u].x + fmaf(b, q[u].x, a), acc[u].y + fmaf(b, q[u].y, a), acc[u].z + fmaf(b, q[u].z, a),
+                                    acc[u].w + fmaf(b, q[u].w, a));
+      }
+    }
+  } else {
+    const uint32_t unit = (uint32_t)L.HW;
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
+      uint32_t plane, j, bidx, c;
+      fast_divmod(begin + i, unit, L.div_unit_mul, L.div_unit_shr, plane, j);
+      fast_divmod(plane, (uint32_t)L.C, L.div_c_mul, L.div_c_shr, bidx, c);
+      const float2 kk = ab[c];
+      o[begin + i] = (gin ? gin[begin + i] : 0.f) + fmaf(g * kk.y, x[begin + i], g * kk.x);
     }
   }
 }
@@ -670,29 +675,38 @@ int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_ho
   BnPtrs ptrs;
   if (!fill_bn_ptrs(ptrs, x_ptrs, n_layers, hw_host)) return BH_EINVAL;
   const int64_t grid = n_fwd_items < g_bn_grid_cap ? n_fwd_items : (int64_t)g_bn_grid_cap;
-  hipLaunchKernelGGL(bn_sums_kernel, dim3((unsigned int)grid), dim3(kBlock), 0, bh::as_stream(stream), ptrs, layers_dev,
-                     fwd_items_dev, (int)n_fwd_items, sums_dev);
+  if (g_bn_load_depth == 4)
+    hipLaunchKernelGGL(bn_sums_kernel<4>, dim3((unsigned int)grid), dim3(kBlock), 0, bh::as_stream(stream), ptrs, layers_dev,
+                       fwd_items_dev, (int)n_fwd_items, sums_dev);
+  else
+    hipLaunchKernelGGL(bn_sums_kernel<8>, dim3((unsigned int)grid), dim3(kBlock), 0, bh::as_stream(stream), ptrs, layers_dev,
+                       fwd_items_dev, (int)n_fwd_items, sums_dev);
   return bh::launch_status();
 }
 
-int bh_bn_sums_finalize(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
-                        const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, const float* running_mean,
-                        const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
-                        void* tickets_dev, void* stream) {
-  if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || x_ptrs == nullptr || hw_host == nullptr || layers_dev == nullptr ||
-      fwd_items_dev == nullptr || n_fwd_items <= 0 || n_fwd_items > INT32_MAX || sums_dev == nullptr ||
-      running_mean == nullptr || running_var == nullptr || coef_dev == nullptr || layer_values_dev == nullptr ||
-      total_dev == nullptr || tickets_dev == nullptr)
+int bh_bn_bwd_accumulate(const float* x, const float* gin, int32_t hw, const bh_bn_layer* layers_dev,
+                         const bh_bn_item* layer_bwd_items_dev, int64_t n_items, const float* coef_dev, const float* gout_dev,
+                         float* out, void* stream) {
+  if (x == nullptr || out == nullptr || layers_dev == nullptr || layer_bwd_items_dev == nullptr || n_items <= 0 ||
+      n_items > INT32_MAX || coef_dev == nullptr || hw <= 0)
     return BH_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(coef_dev) & 7u) != 0) return BH_EINVAL;  // written / read back as float2
-  BnPtrs ptrs;
-  if (!fill_bn_ptrs(ptrs, x_ptrs, n_layers, hw_host)) return BH_EINVAL;
-  const BnFused fz{running_mean, running_var, coef_dev, layer_values_dev, total_dev, static_cast<unsigned int*>(tickets_dev),
-                   n_layers};
-  const int64_t grid = n_fwd_items < g_bn_grid_cap ? n_fwd_items : (int64_t)g_bn_grid_cap;
-  hipLaunchKernelGGL(bn_sums_finalize_kernel, dim3((unsigned int)grid), dim3(kBlock), 0, bh::as_stream(stream), ptrs,
-                     layers_dev, fwd_items_dev, (int)n_fwd_items, sums_dev, fz);
+  if ((hw & 3) == 0 && (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(gin)) & 15u) != 0))
+    return BH_EINVAL;
+  hipLaunchKernelGGL(bn_bwd_acc_kernel, dim3((unsigned int)n_items), dim3(kBlock), 0, bh::as_stream(stream), x, gin, out,
+                     layers_dev, layer_bwd_items_dev, coef_dev, gout_dev);
   return bh::launch_status();
+}
+
+int bh_bn_set_load_depth(int32_t depth) {
+  if (depth != 4 && depth != 8) return BH_EINVAL;
+  g_bn_load_depth = depth;
+  return 0;
+}
+
+int bh_bn_set_finalize_block(int32_t threads) {
+  if (threads != 256 && threads != 512 && threads != 1024) return BH_EINVAL;
+  g_bn_fin_block = threads;
+  return 0;
 }
 
 int bh_bn_set_grid_cap(int32_t cap) {
@@ -709,9 +723,14 @@ int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double
       total_dev == nullptr || counter_dev == nullptr)
     return BH_EINVAL;
   if ((reinterpret_cast<uintptr_t>(coef_dev) & 7u) != 0) return BH_EINVAL;  // read back as float2
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(n_layers), dim3(kBnFinBlock), 0, bh::as_stream(stream), n_layers, layers_dev,
-                     sums_dev, running_mean, running_var, coef_dev, layer_values_dev, total_dev,
-                     static_cast<unsigned int*>(counter_dev));
+#define BH_BN_FIN_LAUNCH(T)                                                                                             \
+  hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(n_layers), dim3(T), 0, bh::as_stream(stream), n_layers, layers_dev,    \
+                     sums_dev, running_mean, running_var, coef_dev, layer_values_dev, total_dev,                        \
+                     static_cast<unsigned int*>(counter_dev))
+  if (g_bn_fin_block == 256) BH_BN_FIN_LAUNCH(256);
+  else if (g_bn_fin_block == 512) BH_BN_FIN_LAUNCH(512);
+  else BH_BN_FIN_LAUNCH(1024);
+#undef BH_BN_FIN_LAUNCH
   return bh::launch_status();
 }
 

@@ -153,6 +153,14 @@ class BnStatPlan:
         w = (c_float * n)(*[float(v) for v in weights])
         _lib.check(lib.bh_bn_plan_build(n, B, C, self.hw_host, w, layers, fwd, self.n_fwd, bwd, self.n_bwd), "bh_bn_plan_build")
         self.flat_offsets = [layers[i].flat_off for i in range(n)]
+        # per layer: first backward item and item count (the table is built layer by layer) -- the per-layer fused
+        # backward-accumulate launches address their slice of it
+        counts = [0] * n
+        for item in bwd:
+            counts[item.layer] += 1
+        self.bwd_counts = counts
+        self.bwd_begins = [sum(counts[:i]) for i in range(n)]
+        self.item_bytes = ctypes.sizeof(_lib.BnItem)
         self.numels = [int(torch.Size(s).numel()) for s in shapes]
         self.layers_dev, self.fwd_dev, self.bwd_dev = _upload(layers, device), _upload(fwd, device), _upload(bwd, device)
         self.running_mean = torch.cat([m.detach().to(torch.float32).reshape(-1) for m in running_means]).contiguous()
@@ -165,18 +173,6 @@ class BnStatPlan:
         from ctypes import c_void_p
 
         return (c_void_p * self.n_layers)(*[x.data_ptr() for x in xs])
-
-
-def bn_fused_forward():
-    """One launch (sums + per-layer finalize by the last arriver, `bh_bn_sums_finalize`) or two (`bh_bn_sums`, `bh_bn_finalize`)
-    for the forward stage of kernel D: BREACH_HIP_BN_FUSED=1 / 0, default set from the round-3 measurement
-    (profiles/r3_kernel_bench.json)."""
-    import os
-
-    return os.environ.get("BREACH_HIP_BN_FUSED", BN_FUSED_DEFAULT) != "0"
-
-
-BN_FUSED_DEFAULT = "0"
 
 
 class _BnStatFunction(torch.autograd.Function):
@@ -202,19 +198,13 @@ class _BnStatFunction(torch.autograd.Function):
             coef = torch.empty(2 * plan.n_channels, dtype=torch.float32, device=dev)
             total = torch.empty(1, dtype=torch.float32, device=dev)
             if ticket is None:
-                ticket = torch.zeros(plan.n_layers + 1, dtype=torch.int32, device=dev)
+                ticket = torch.zeros(1, dtype=torch.int32, device=dev)
             ptrs = plan.pointers(prepared)
-            if bn_fused_forward():
-                _lib.check(lib.bh_bn_sums_finalize(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
-                                                   plan.n_fwd, _lib.ptr(sums), _lib.ptr(plan.running_mean), _lib.ptr(plan.running_var),
-                                                   _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total), _lib.ptr(ticket), stream),
-                           "bh_bn_sums_finalize")
-            else:
-                _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
-                                          plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
-                _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
-                                              _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
-                                              _lib.ptr(ticket), stream), "bh_bn_finalize")
+            _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
+                                      plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
+            _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
+                                          _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
+                                          _lib.ptr(ticket), stream), "bh_bn_finalize")
         ctx.plan = plan
         ctx.save_for_backward(coef, *prepared)
         ctx.in_shapes = [x.shape for x in xs]
@@ -237,6 +227,101 @@ class _BnStatFunction(torch.autograd.Function):
         return (None, None, *grads)
 
 
+def accumulate_in_kernel():
+    """BREACH_HIP_BN_TAPS=0 restores round 2's backward of the DeepInversion prior (one launch writing all layers' gradients,
+    one ATen `add` per layer by autograd) for before / after profiles; default: the taps' fused read-modify-write."""
+    import os
+
+    return os.environ.get("BREACH_HIP_BN_TAPS", "1") != "0"
+
+
+class _BnTapRecord:
+    """What the taps of one model and the statistic node share during one evaluation: the plan, the coefficient array the
+    finalize kernel wrote, and per layer the activation the tap saw."""
+
+    def __init__(self):
+        self.plan = None
+        self.coef = None
+
+
+class _BnTap(torch.autograd.Function):
+    """Identity on a BatchNorm input with two jobs.  Forward: hand the activation to kernel D (no copy) and emit a 0-dim
+    token through which the statistic node later sends back d objective / d total.  Backward: when that token gradient
+    arrives, write `incoming gradient + gout * (A_c + B_c * x)` in ONE launch (bh_bn_bwd_accumulate) -- the read-modify-write
+    of SURVEY section 8(d) stays inside our kernel instead of costing autograd one `add` launch per layer on top of ours.
+    Without a token gradient (the first-order pass under create_graph=True, scoring, any pass the prior is not part of) the
+    tap is a differentiable no-op."""
+
+    @staticmethod
+    def forward(ctx, x, record, layer):
+        ctx.record, ctx.layer = record, layer
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x)
+        return x.view_as(x), x.new_empty(())
+
+    @staticmethod
+    def backward(ctx, g_x, g_token):
+        if g_token is None:
+            return g_x, None, None
+        (x,) = ctx.saved_tensors
+        plan, coef = ctx.record.plan, ctx.record.coef
+        if plan is None or coef is None:
+            raise RuntimeError("DeepInversion tap received a gradient without a forward evaluation of the statistic.")
+        lib = _lib.load()
+        layer = ctx.layer
+        x = x.detach()
+        if not x.is_contiguous():
+            x = x.contiguous()
+        gin = None
+        if g_x is not None:
+            gin = g_x.detach()
+            if gin.dtype != torch.float32 or not gin.is_contiguous() or (plan.hw_host[layer] % 4 == 0 and gin.data_ptr() % 16):
+                gin = gin.to(torch.float32).contiguous().clone()
+        out = torch.empty_like(x)
+        gout = g_token.detach().reshape(1).to(torch.float32)
+        dev = plan.device
+        items = ctypes_offset(plan.bwd_dev, plan.bwd_begins[layer] * plan.item_bytes)
+        with torch.cuda.device(dev):
+            _lib.check(lib.bh_bn_bwd_accumulate(_lib.ptr(x), _lib.ptr(gin), plan.hw_host[layer], _lib.ptr(plan.layers_dev), items,
+                                                plan.bwd_counts[layer], _lib.ptr(coef), _lib.ptr(gout), _lib.ptr(out),
+                                                _lib.current_stream_handle(dev)), "bh_bn_bwd_accumulate")
+        return out, None, None
+
+
+class _BnStatTokenFunction(torch.autograd.Function):
+    """total = sum_l weight_l * r_l(x_l) over the activations the taps recorded: two launches forward (bh_bn_sums,
+    bh_bn_finalize).  Its autograd inputs are the taps' tokens: backward only forwards d objective / d total to every tap,
+    which then does the per-layer read-modify-write."""
+
+    @staticmethod
+    def forward(ctx, plan, ticket, record, xs, *tokens):
+        lib = _lib.load()
+        dev = plan.device
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream_handle(dev)
+            sums = torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=dev)
+            layer_values = torch.empty(plan.n_layers, dtype=torch.float64, device=dev)
+            coef = torch.empty(2 * plan.n_channels, dtype=torch.float32, device=dev)
+            total = torch.empty(1, dtype=torch.float32, device=dev)
+            if ticket is None:
+                ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+            ptrs = plan.pointers(xs)
+            _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
+                                      plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
+            _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
+                                          _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
+                                          _lib.ptr(ticket), stream), "bh_bn_finalize")
+        record.plan, record.coef = plan, coef
+        ctx.n_tokens = len(tokens)
+        return total[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        gout = gout.contiguous().to(torch.float32)
+        return (None, None, None, None, *([gout] * ctx.n_tokens))
+
+
 def bn_statistic(x, running_mean, running_var, weight=1.0):
     """The statistic of a single BatchNorm input (a one-layer plan): used by the kernel tests."""
     plan = BnStatPlan([x.shape], [running_mean], [running_var], [weight], x.device)
@@ -249,17 +334,29 @@ def ctypes_offset(tensor, elements):
     return c_void_p(tensor.data_ptr() + elements * tensor.element_size())
 
 
-class _BnInputHook:
-    """Forward hook on one BatchNorm2d: keeps the module's *input* of the latest forward pass (the reference computes the
-    statistic right inside its hook, deepinversion.py:93-101; here all layers are evaluated together afterwards)."""
+class _BnInputTap:
+    """Forward pre-hook on one BatchNorm2d: routes the module's *input* through `_BnTap` (the reference computes the
+    statistic right inside its forward hook, deepinversion.py:93-101; here all layers are evaluated together afterwards,
+    and the tap is where their gradient re-enters the graph)."""
 
-    def __init__(self, module):
-        self.module = module
-        self.x = None
-        self.handle = module.register_forward_hook(self)
+    def __init__(self, module, record, layer):
+        self.module, self.record, self.layer = module, record, layer
+        self.x = None      # the activation of the latest forward pass (detached view, what kernel D reads)
+        self.token = None  # its token (carries the autograd edge back to the tap)
+        self.live = None   # the same activation with its autograd history (only the A/B switch below uses it)
+        self.handle = module.register_forward_pre_hook(self)
 
-    def __call__(self, module, inputs, output):
-        self.x = inputs[0]
+    def __call__(self, module, inputs):
+        x = inputs[0]
+        if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32):
+            raise RuntimeError("HIP DeepInversion prior needs fp32 activations on a ROCm device (no CPU fallback).")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        if x.dim() > 2 and x[0, 0].numel() % 4 == 0 and x.data_ptr() % 16:
+            x = x.clone()  # 16-byte vector loads need an aligned base
+        tapped, token = _BnTap.apply(x, self.record, self.layer)
+        self.x, self.token, self.live = tapped.detach(), token, tapped
+        return (tapped, *inputs[1:])
 
     def close(self):
         self.handle.remove()
@@ -284,17 +381,20 @@ class HipDeepInversion(torch.nn.Module):
             for hook in hooks:
                 hook.close()
         self.losses = [list() for _ in models]
+        self._records = [_BnTapRecord() for _ in models]
         self._plans = {}
         for idx, model in enumerate(models):
             for module in model.modules():
                 if isinstance(module, torch.nn.BatchNorm2d):
-                    self.losses[idx].append(_BnInputHook(module))
+                    self.losses[idx].append(_BnInputTap(module, self._records[idx], len(self.losses[idx])))
 
     def release_graph(self):
         """Drop the activations of the last forward pass (they hold that pass's autograd graph)."""
         for hooks in self.losses:
             for hook in hooks:
-                hook.x = None
+                hook.x = hook.token = hook.live = None
+        for record in getattr(self, "_records", []):
+            record.coef = None
 
     def _plan(self, idx, hooks, xs):
         shapes = [x.shape for x in xs]
@@ -322,9 +422,12 @@ class HipDeepInversion(torch.nn.Module):
             if self.ticket_scope is not None:
                 ticket = self.ticket_scope.get(("bn", idx))
                 if ticket is None:
-                    # one word per layer + one for the model (the fused forward signs per layer; the two-launch one uses word 0)
-                    ticket = self.ticket_scope[("bn", idx)] = torch.zeros(plan.n_layers + 1, dtype=torch.int32, device=plan.device)
-            total = total + _BnStatFunction.apply(plan, ticket, *xs)
+                    ticket = self.ticket_scope[("bn", idx)] = torch.zeros(1, dtype=torch.int32, device=plan.device)
+            if accumulate_in_kernel():
+                tokens = [hook.token for hook in hooks]
+                total = total + _BnStatTokenFunction.apply(plan, ticket, self._records[idx], xs, *tokens)
+            else:  # round-2 form, kept for A/B measurements: one backward launch for all layers, autograd adds each layer in
+                total = total + _BnStatFunction.apply(plan, ticket, *[hook.live for hook in hooks])
         return total
 
     def __repr__(self):

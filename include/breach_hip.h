@@ -198,7 +198,7 @@ typedef struct bh_bn_layer { /* 64 bytes, device resident, built once per attack
   float weight;          /* weight_l */
   uint32_t div_unit_mul, div_unit_shr; /* fast division by HW/4 (HW % 4 == 0) or HW */
   uint32_t div_c_mul, div_c_shr;       /* fast division by C */
-  int32_t fwd_items;     /* forward items (workgroups of stage 1) of this layer: the arrival count of its ticket */
+  int32_t fwd_items;     /* forward items (stage 1) of this layer */
 } bh_bn_layer;
 
 typedef struct bh_bn_item { /* 16 bytes: forward (layer, channel [first of 4 when narrow], slab, -); */
@@ -219,6 +219,13 @@ int bh_bn_plan_build(int32_t n_layers, const int32_t* B, const int32_t* C, const
 int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
                const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, void* stream);
 
+#define BH_BN_DEFAULT_FINALIZE_BLOCK 1024
+/* Tuning knob of stage 2 (process wide): threads per layer workgroup, 256 / 512 / 1024. */
+int bh_bn_set_finalize_block(int32_t threads);
+
+/* Tuning knob of stage 1 (process wide): 16-byte loads in flight per thread, 4 or 8 (default 8). */
+int bh_bn_set_load_depth(int32_t depth);
+
 /* Tuning knob of stage 1 (process wide, default BH_BN_DEFAULT_GRID): workgroups of the persistent forward grid. */
 int bh_bn_set_grid_cap(int32_t cap);
 
@@ -231,21 +238,20 @@ int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double
                    const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
                    void* counter_dev, void* stream);
 
-/* Stages 1 + 2 in ONE launch: every stage-1 workgroup signs its layer's ticket after writing its sums; the workgroup that
- * arrives last at a layer finalises that layer (as stage 2 does), and the last layer to finish adds the layers up in index
- * order.  `tickets_dev`: n_layers + 1 zeroed uint32 words (re-zeroed by the kernel).  Same per-layer arithmetic as
- * bh_bn_sums + bh_bn_finalize in fixed (run-to-run reproducible) orders; the layer norms are combined by 256 instead of
- * 1024 threads, so the two variants agree to fp64 rounding of the norms (identical after the cast to fp32 in practice). */
-int bh_bn_sums_finalize(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
-                        const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, const float* running_mean,
-                        const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
-                        void* tickets_dev, void* stream);
-
 /* Backward of all layers in one launch: grad_flat[flat_off_l + i] = gout * (A_c + B_c * x_l[i]); gout read from
  * *gout_dev (NULL = 1).  grad_flat (16-byte aligned, flat_elems floats) is overwritten. */
 int bh_bn_bwd(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
               const bh_bn_item* bwd_items_dev, int64_t n_bwd_items, const float* coef_dev, const float* gout_dev,
               float* grad_flat, void* stream);
+
+/* Backward of ONE layer fused with the accumulation into the activation gradient: out[i] = gin[i] + gout * (A_c + B_c * x[i])
+ * over the layer's n_items backward items (`layer_bwd_items_dev` points at the first of them inside the plan's table);
+ * gin may be NULL (nothing else reached this activation), gout is read from *gout_dev (NULL = 1).  x / gin / out: the
+ * layer's [B, C, HW] fp32 arrays (16-byte aligned when hw % 4 == 0); out may not alias x.  This is the read-modify-write
+ * autograd otherwise does with one `add` per BatchNorm input (regularizers.py:222-227 summed into the main gradient). */
+int bh_bn_bwd_accumulate(const float* x, const float* gin, int32_t hw, const bh_bn_layer* layers_dev,
+                         const bh_bn_item* layer_bwd_items_dev, int64_t n_items, const float* coef_dev, const float* gout_dev,
+                         float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Multi-tensor elementwise kernels over per-parameter lists (FedAvg unroll, Pearlmutter offset) and batch kernels

@@ -25,6 +25,11 @@ if args.only is None and args.per_process:
 # fixed in round 3, see attacker._run_trial_group and profiles/r3_stall_bisect.jsonl.)
 dev = torch.device("cuda:0")
 setup = dict(device=dev, dtype=torch.float)
+# kernel D tuning knobs for same-box A/B profiles (scripts/r3_call10.sh)
+from breaching_amd import _lib as _bh_lib
+for env, setter in (("BN_DEPTH", "bh_bn_set_load_depth"), ("BN_GRID_CAP", "bh_bn_set_grid_cap"), ("BN_FIN_BLOCK", "bh_bn_set_finalize_block")):
+    if env in os.environ:
+        assert getattr(_bh_lib.load(), setter)(int(os.environ[env])) == 0, env
 out = {}
 
 

@@ -155,7 +155,7 @@ sums = torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=dev)
 layer_values = torch.empty(plan.n_layers, dtype=torch.float64, device=dev)
 coef = torch.empty(2 * plan.n_channels, device=dev)
 total_out = torch.empty(1, device=dev)
-ticket = torch.zeros(plan.n_layers + 1, dtype=torch.int32, device=dev)
+ticket = torch.zeros(1, dtype=torch.int32, device=dev)
 grad_flat = torch.empty(plan.flat_elems, device=dev)
 ptrs = plan.pointers(acts)
 def d_sums():
@@ -167,26 +167,14 @@ def d_fin():
                                   _lib.ptr(ticket), _lib.current_stream_handle(dev)), "finalize")
 def d_fwd():
     d_sums(); d_fin()
-def d_fused():
-    _lib.check(lib.bh_bn_sums_finalize(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev), plan.n_fwd,
-                                       _lib.ptr(sums), _lib.ptr(plan.running_mean), _lib.ptr(plan.running_var), _lib.ptr(coef),
-                                       _lib.ptr(layer_values), _lib.ptr(total_out), _lib.ptr(ticket), _lib.current_stream_handle(dev)), "fused")
 def d_bwd():
     _lib.check(lib.bh_bn_bwd(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.bwd_dev), plan.n_bwd,
                              _lib.ptr(coef), None, _lib.ptr(grad_flat), _lib.current_stream_handle(dev)), "bwd")
 us_s, us_fin = burst(d_sums, reps=20, warm=3), burst(d_fin, reps=20, warm=3)
 us_f, us_b = burst(d_fwd, reps=20, warm=3), burst(d_bwd, reps=20, warm=3)
-d_fwd(); torch.cuda.synchronize()
-two_launch = (float(total_out), coef.clone())
-total_out.zero_(); coef.zero_()
-us_fused = burst(d_fused, reps=20, warm=3)
-fused_diff = dict(total_rel=abs(float(total_out) - two_launch[0]) / abs(two_launch[0]),
-                  coef_max_abs=float((coef - two_launch[1]).abs().max()), ticket_clean=bool((ticket == 0).all()))
 out["kernelD_resnet50_B8"] = dict(layers=len(acts), elements=total, fwd_items=plan.n_fwd, bwd_items=plan.n_bwd,
                                   sums_us=round(us_s, 1), finalize_us=round(us_fin, 1),
                                   fwd_us=round(us_f, 1), fwd_GBs=round(total * 4 / us_f / 1e3, 1),
-                                  fused_fwd_us=round(us_fused, 1), fused_fwd_GBs=round(total * 4 / us_fused / 1e3, 1),
-                                  fused_vs_two_launch=fused_diff,
                                   bwd_us=round(us_b, 1), bwd_GBs=round(2 * total * 4 / us_b / 1e3, 1),
                                   note="one sums launch + one finalize launch forward, one launch backward for all 53 layers "
                                        "(burst of back-to-back launches; 355.6 MB read forward, read + written backward)")
@@ -196,4 +184,10 @@ for cap in (512, 1024, 2048, 4096, 1 << 20):
     sweep[str(cap)] = round(burst(d_sums, reps=20, warm=3), 1)
 lib.bh_bn_set_grid_cap(1 << 20)
 out["kernelD_resnet50_B8"]["sums_us_by_grid_cap"] = sweep
+fin = {}
+for threads in (256, 512, 1024):
+    lib.bh_bn_set_finalize_block(threads)
+    fin[str(threads)] = dict(finalize_us=round(burst(d_fin, reps=20, warm=3), 1), stage_us=round(burst(d_fwd, reps=20, warm=3), 1))
+lib.bh_bn_set_finalize_block(1024)
+out["kernelD_resnet50_B8"]["finalize_by_block_threads"] = fin
 print(json.dumps(out, indent=1))

@@ -5,7 +5,7 @@
 import csv, os, sys, collections
 
 OURS = ("gm_fwd_kernel", "gm_bwd_kernel", "gm_finalize_kernel", "tv_norm_kernel", "candidate_step_kernel", "loss_commit_kernel",
-        "bn_sums_kernel", "bn_finalize_kernel", "bn_bwd_kernel", "grad_sumsq", "gm_pack_kernel", "state_reset")
+        "bn_sums_kernel", "bn_finalize_kernel", "bn_bwd_kernel", "bn_bwd_acc_kernel", "mt_kernel", "orthogonality_kernel", "psnr_mse_kernel", "grad_sumsq", "gm_pack_kernel", "state_reset")
 src, out = sys.argv[1], sys.argv[2]
 counter = sys.argv[3] if len(sys.argv) > 3 else None
 files = {f: os.path.join(src, f) for f in os.listdir(src)}

@@ -19,7 +19,7 @@ def _declared_functions():
 def test_header_declares_the_expected_surface():
     names = _declared_functions()
     for required in ("bh_gm_fwd", "bh_gm_bwd", "bh_gm_finalize", "bh_gm_pack", "bh_prior_tv_norm", "bh_bn_sums",
-                     "bh_bn_finalize", "bh_bn_sums_finalize", "bh_bn_bwd", "bh_bn_plan_build", "bh_gm_fwd_rows", "bh_loss_commit", "bh_candidate_step", "bh_grad_norm",
+                     "bh_bn_finalize", "bh_bn_bwd", "bh_bn_plan_build", "bh_gm_fwd_rows", "bh_loss_commit", "bh_candidate_step", "bh_grad_norm",
                      "bh_state_reset", "bh_abi_version"):
         assert required in names
 
@@ -180,7 +180,7 @@ def test_bn_plan_host_tables(hip_lib):
         assert covered[l] * (4 if hw % 4 == 0 else 1) == b * c * hw
         assert (L.B, L.C, L.HW, L.weight) == (b, c, hw, 1.0 + l) and L.flat_off % 4 == 0
         assert bool(L.narrow) == (b * hw < 2048)
-        assert L.fwd_items == sum(1 for it in fwd if it.layer == l)  # arrival count of the layer's ticket (fused forward)
+        assert L.fwd_items == sum(1 for it in fwd if it.layer == l)
         for d, mul, shr in ((unit, L.div_unit_mul, L.div_unit_shr), (c, L.div_c_mul, L.div_c_shr)):
             top = b * c * unit
             for v in {0, 1, d - 1, d, d + 1, 2 * d - 1, top - 1, top // 2, (1 << 31) - 1} | set(range(max(top - 3 * d, 0), top, max(d // 3, 1))):

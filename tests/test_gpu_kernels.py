@@ -191,15 +191,8 @@ def test_tv_norm_matches_c_oracle(shape, opp, kernels_oracle, hip_lib):
     _assert_grads([grad.cpu().numpy()], [want_g], rtol=1e-6)
 
 
-@pytest.fixture(params=["two-launch", "fused"])
-def bn_forward_variant(request, monkeypatch):
-    """Kernel D's forward stage both ways: bh_bn_sums + bh_bn_finalize, and the single launch bh_bn_sums_finalize."""
-    monkeypatch.setenv("BREACH_HIP_BN_FUSED", "1" if request.param == "fused" else "0")
-    return request.param
-
-
 @pytest.mark.parametrize("tag", ["a", "b"])
-def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib, bn_forward_variant):
+def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib):
     from breaching_amd.priors import bn_statistic
 
     gold = np.load(os.path.join(golden_dir, "kernels.npz"))
@@ -214,7 +207,7 @@ def test_bnstat_matches_reference_golden(tag, golden_dir, hip_lib, bn_forward_va
 
 
 @pytest.mark.parametrize("shape", [(8, 64, 112, 112), (8, 2048, 7, 7), (2, 256, 14, 14), (1, 3, 5, 5)])
-def test_bnstat_matches_c_oracle(shape, kernels_oracle, hip_lib, bn_forward_variant):
+def test_bnstat_matches_c_oracle(shape, kernels_oracle, hip_lib):
     from breaching_amd.priors import bn_statistic
     from oracle import kernels_ref
 
@@ -323,7 +316,7 @@ def test_candidate_step_best_copy_is_post_step_candidate(kernels_oracle, hip_lib
     np.testing.assert_allclose(r["best"], r["best_o"], rtol=2e-5, atol=2e-6)
 
 
-def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_lib, bn_forward_variant):
+def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_lib):
     """Kernel D over a whole model's BatchNorm inputs at once: wide (whole workgroup per channel slab), narrow (one wavefront
     per channel), vectorised and scalar (H*W % 4 != 0) layers mixed; total = sum_l w_l * r_l and every layer's gradient."""
     from breaching_amd.priors import BnStatPlan, _BnStatFunction
@@ -338,7 +331,7 @@ def test_bnstat_all_layers_in_one_launch_matches_c_oracle(kernels_oracle, hip_li
     xs = [torch.tensor(x, device=_dev(), requires_grad=True) for x in xs_np]
     plan = BnStatPlan([x.shape for x in xs], [torch.tensor(m, device=_dev()) for m in rms],
                       [torch.tensor(v, device=_dev()) for v in rvs], weights, _dev())
-    ticket = torch.zeros(plan.n_layers + 1, dtype=torch.int32, device=_dev())
+    ticket = torch.zeros(1, dtype=torch.int32, device=_dev())
     for _ in range(3):  # the ticket words are re-zeroed by the kernel: later calls must work like the first
         total = _BnStatFunction.apply(plan, ticket, *xs)
         grads = torch.autograd.grad(total * 0.7, xs)
@@ -504,3 +497,64 @@ def test_multi_tensor_axpy_scale_and_fedavg_step_function(hip_lib):
         else:
             assert gp is None or float(gp.abs().max()) == 0.0
             assert gg is None or float(gg.abs().max()) == 0.0
+
+
+def test_deepinversion_taps_accumulate_into_the_activation_gradient(kernels_oracle, hip_lib):
+    """The product path of kernel D's backward: every BatchNorm input runs through a tap whose backward writes
+    `incoming gradient + gout * (A_c + B_c * x)` in one launch (bh_bn_bwd_accumulate) instead of leaving the sum to autograd.
+    A small conv / BN stack (wide, narrow, H*W % 4 != 0 layers): value and d/d input of `loss_main + 0.7 * prior` against
+    autograd through the same model with the prior's gradient taken from the C oracle, layer by layer; the first-order pass
+    under create_graph=True (which the attack's double backward needs) goes through the taps untouched."""
+    from breaching_amd.priors import HipDeepInversion
+    from oracle import kernels_ref
+
+    torch.manual_seed(3)
+    dev = _dev()
+    model = torch.nn.Sequential(
+        torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.Tanh(),
+        torch.nn.Conv2d(8, 12, 3, stride=2, padding=1), torch.nn.BatchNorm2d(12), torch.nn.Tanh(),
+        torch.nn.Conv2d(12, 6, 3, stride=2, padding=0), torch.nn.BatchNorm2d(6)).to(dev).eval()
+    bns = [m for m in model if isinstance(m, torch.nn.BatchNorm2d)]
+    for i, bn in enumerate(bns):
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(4, 3, 56, 56, device=dev, requires_grad=True)  # BN inputs: [4,8,56,56] wide, [4,12,28,28] wide, [4,6,13,13] narrow + scalar
+    prior = HipDeepInversion(dict(device=dev, dtype=torch.float), scale=0.25, first_bn_multiplier=10)
+    prior.initialize([model])
+    # reference: plain autograd through the same model, the prior's per-layer value / gradient from the C oracle
+    acts = []
+    hooks = [bn.register_forward_hook(lambda m, i, o: acts.append(i[0])) for bn in bns]
+    out = model(x)
+    main = (out ** 2).mean()
+    value = prior(x)
+    total = main + 0.7 * value
+    (got,) = torch.autograd.grad(total, x)
+    want_value, stat_grads = 0.0, []
+    for i, (a, bn) in enumerate(zip(acts, bns)):
+        w = 0.25 * (10 if i == 0 else 1)
+        v, g, _, _ = kernels_ref.bnstat(a.detach().cpu().numpy(), bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy())
+        want_value += w * v
+        stat_grads.append(torch.tensor(0.7 * w * g, dtype=torch.float32, device=dev))
+    assert abs(value.item() - want_value) <= 2e-6 * abs(want_value)
+    for h in hooks:
+        h.remove()
+    prior.initialize([])  # drop the taps: a plain model again
+    acts.clear()
+    hooks = [bn.register_forward_hook(lambda m, i, o: acts.append(i[0])) for bn in bns]
+    x2 = x.detach().clone().requires_grad_(True)
+    main2 = (model(x2) ** 2).mean()
+    (want,) = torch.autograd.grad([main2, *acts], x2, grad_outputs=[torch.ones_like(main2), *stat_grads])
+    for h in hooks:
+        h.remove()
+    _assert_grads([got.cpu().numpy()], [want.cpu().numpy().astype(np.float64)], rtol=2e-5)
+    # first-order pass with create_graph=True through live taps, then a second-order gradient: identical to the tap-free model
+    prior.initialize([model])
+    xa = x.detach().clone().requires_grad_(True)
+    (ga,) = torch.autograd.grad((model(xa) ** 2).mean(), xa, create_graph=True)
+    (gga,) = torch.autograd.grad((ga ** 2).sum(), xa)
+    prior.initialize([])
+    xb = x.detach().clone().requires_grad_(True)
+    (gb,) = torch.autograd.grad((model(xb) ** 2).mean(), xb, create_graph=True)
+    (ggb,) = torch.autograd.grad((gb ** 2).sum(), xb)
+    torch.testing.assert_close(ga, gb, rtol=0, atol=0)
+    torch.testing.assert_close(gga, ggb, rtol=1e-6, atol=1e-9)
