@@ -16,7 +16,6 @@ BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
 BH_GM_MAX_ROWS = 2048
 BH_GM_DEFAULT_ROWS = 512
-BH_GM_DEFAULT_PIPELINE = 2
 BH_GM_STAT_WORDS = 12
 BH_PRIOR_MAX_GRID = 1024
 BH_BN_MAX_LAYERS = 448
@@ -93,7 +92,6 @@ _PROTOTYPES = {
     ),
     "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32)]),
     "bh_gm_set_rows_cap": (c_int32, [c_int32]),
-    "bh_gm_set_pipeline": (c_int, [c_int32]),
     "bh_gm_finalize": (
         c_int,
         [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

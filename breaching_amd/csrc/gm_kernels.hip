@@ -189,58 +189,12 @@ __device__ void gm_combine_rows(int kind, const double* __restrict__ partials, i
   gm_epilogue(kind, v, scale, tag_scale, fudge, fd_eps, span_ticks, stats);
 }
 
-// One chunk's contribution to the workgroup's running sums.  `rv` / `dv`: the chunk's values when it is a full chunk whose
-// loads were issued ahead of time (PREFETCHED); otherwise the chunk is read here.  The arithmetic per chunk is the same in
-// every pipelining mode: two fp32 accumulator sets of at most 16 values each, combined in fp64 -- results do not depend on
-// the mode.
-template <int KIND, bool PREFETCHED>
-__device__ __forceinline__ void gm_chunk_sums(const bh_gm_chunk& ch, const float* __restrict__ r, const float* __restrict__ d,
-                                              const float4 (&rv_in)[kVecPerThread], const float4 (&dv_in)[kVecPerThread],
-                                              const float* __restrict__ weights, float tag_scale, int tid, double (&acc)[3]) {
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(r);
-  const float4* __restrict__ d4 = reinterpret_cast<const float4*>(d);
-  if (ch.len == BH_GM_CHUNK) {
-    float4 rv[kVecPerThread], dv[kVecPerThread];
-    if constexpr (PREFETCHED) {
-#pragma unroll
-      for (int k = 0; k < kVecPerThread; ++k) {
-        rv[k] = rv_in[k];
-        dv[k] = dv_in[k];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
-#pragma unroll
-      for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
-    }
-#pragma unroll
-    for (int k = 0; k < kVecPerThread; k += 2) {
-      accumulate4<KIND>(rv[k], dv[k], a0, a1, a2);
-      if (k + 1 < kVecPerThread) accumulate4<KIND>(rv[k + 1], dv[k + 1], b0, b1, b2);
-    }
-  } else {
-    const int n4 = ch.len >> 2;
-    for (int i = tid; i < n4; i += kBlock) accumulate4<KIND>(r4[i], d4[i], a0, a1, a2);
-    const int tail = ch.len & 3;
-    if (tid < tail) accumulate<KIND>(r[(n4 << 2) + tid], d[(n4 << 2) + tid], b0, b1, b2);
-  }
-  const double s0 = (double)a0 + (double)b0, s1 = (double)a1 + (double)b1, s2 = (double)a2 + (double)b2;
-  if constexpr (KIND == BH_GM_TAG) {
-    // objectives.py:139-140: (rec-data).pow(2).sum() + tag_scale * weight * (rec-data).abs().sum(), weight per tensor
-    acc[0] += s0 + (double)tag_scale * (double)weights[ch.tensor] * s1;
-  } else {
-    acc[0] += s0;
-  }
-  acc[1] += s1;
-  acc[2] += s2;
-}
-
-// PIPE = 0: round 2's loop (descriptor -> loads -> sums, one chunk at a time).  PIPE = 1: the next chunk's descriptor is
-// fetched while the current chunk streams.  PIPE = 2: descriptors two chunks ahead and the next FULL chunk's eight 16-byte
-// loads issued before the current chunk is summed -- a wave keeps two chunks (16 KB) in flight instead of one and never
-// waits on a descriptor.  bh_gm_set_pipeline selects the mode; results are bit-identical across modes.
-template <int KIND, int PIPE>
+// Measured and rejected in round 3 (commit 03d1fef, profiles/r3_kernel_bench_pipeline_sweep.json): software pipelining of
+// the chunk loop -- next descriptor prefetched (mode 1), descriptors two ahead plus the next full chunk's loads issued
+// before the current chunk is summed (mode 2).  ResNet-18 16.2 / 16.0 / 16.8 us, ResNet-50 31.1 / 31.1 / 32.6 us, BERT-base
+// 111 / 110 / 115 us for modes 0 / 1 / 2: the eight waves per CU already overlap each other's descriptor and data latency, the
+// extra registers of mode 2 (112 VGPRs) buy nothing.  The plain loop stays.
+template <int KIND>
 __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
                                                         const bh_gm_chunk* __restrict__ chunks, int chunk_begin,
                                                         int chunk_end, const float* __restrict__ weights, float tag_scale,
@@ -250,70 +204,40 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
   // constant-rate wall clock at block entry (thread 0 only): lets the combine step report the launch's true span
   const unsigned int tick0 = tid == 0 ? (unsigned int)wall_clock64() : 0u;
   double acc[3] = {0.0, 0.0, 0.0};  // per-thread sums across this workgroup's chunks
-  const int stride = (int)gridDim.x;
-  int c = chunk_begin + (int)blockIdx.x;
-  float4 none[kVecPerThread];
-  if constexpr (PIPE == 0) {
-    for (; c < chunk_end; c += stride) {
-      const bh_gm_chunk ch = chunks[c];
-      gm_chunk_sums<KIND, false>(ch, ptrs.p[ch.tensor - tensor_base] + ch.tensor_off, data_flat + ch.flat_off, none, none, weights,
-                                 tag_scale, tid, acc);
-    }
-  } else if constexpr (PIPE == 1) {
-    if (c < chunk_end) {
-      bh_gm_chunk ch = chunks[c];
-      for (; c < chunk_end; c += stride) {
-        const int cn = c + stride;
-        const bh_gm_chunk ch_next = chunks[cn < chunk_end ? cn : c];
-        gm_chunk_sums<KIND, false>(ch, ptrs.p[ch.tensor - tensor_base] + ch.tensor_off, data_flat + ch.flat_off, none, none,
-                                   weights, tag_scale, tid, acc);
-        ch = ch_next;
-      }
-    }
-  } else {
-    if (c < chunk_end) {
-      const int last = chunk_end - 1;
-      bh_gm_chunk ch = chunks[c];
-      bh_gm_chunk ch1 = chunks[c + stride <= last ? c + stride : c];
+  for (int c = chunk_begin + blockIdx.x; c < chunk_end; c += gridDim.x) {
+    const bh_gm_chunk ch = chunks[c];
+    const float* __restrict__ r = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
+    const float* __restrict__ d = data_flat + ch.flat_off;
+    // two independent fp32 accumulator sets keep the fma chains short; at most 16 values each before going to fp64
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    const float4* __restrict__ r4 = reinterpret_cast<const float4*>(r);
+    const float4* __restrict__ d4 = reinterpret_cast<const float4*>(d);
+    if (ch.len == BH_GM_CHUNK) {
       float4 rv[kVecPerThread], dv[kVecPerThread];
-      bool have = ch.len == BH_GM_CHUNK;
-      if (have) {
-        const float4* __restrict__ r4 = reinterpret_cast<const float4*>(ptrs.p[ch.tensor - tensor_base] + ch.tensor_off);
-        const float4* __restrict__ d4 = reinterpret_cast<const float4*>(data_flat + ch.flat_off);
 #pragma unroll
-        for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
+      for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
 #pragma unroll
-        for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
+      for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
+#pragma unroll
+      for (int k = 0; k < kVecPerThread; k += 2) {
+        accumulate4<KIND>(rv[k], dv[k], a0, a1, a2);
+        if (k + 1 < kVecPerThread) accumulate4<KIND>(rv[k + 1], dv[k + 1], b0, b1, b2);
       }
-      for (; c < chunk_end; c += stride) {
-        const int c1 = c + stride, c2 = c + 2 * stride;
-        const bh_gm_chunk ch2 = chunks[c2 <= last ? c2 : c];  // descriptor two ahead
-        float4 rn[kVecPerThread], dn[kVecPerThread];
-        const bool have_next = c1 <= last && ch1.len == BH_GM_CHUNK;
-        if (have_next) {  // the next full chunk's loads go out before this chunk is summed
-          const float4* __restrict__ r4 = reinterpret_cast<const float4*>(ptrs.p[ch1.tensor - tensor_base] + ch1.tensor_off);
-          const float4* __restrict__ d4 = reinterpret_cast<const float4*>(data_flat + ch1.flat_off);
-#pragma unroll
-          for (int k = 0; k < kVecPerThread; ++k) rn[k] = r4[tid + k * kBlock];
-#pragma unroll
-          for (int k = 0; k < kVecPerThread; ++k) dn[k] = d4[tid + k * kBlock];
-        }
-        const float* r = ptrs.p[ch.tensor - tensor_base] + ch.tensor_off;
-        const float* d = data_flat + ch.flat_off;
-        if (have) gm_chunk_sums<KIND, true>(ch, r, d, rv, dv, weights, tag_scale, tid, acc);
-        else gm_chunk_sums<KIND, false>(ch, r, d, none, none, weights, tag_scale, tid, acc);
-        if (have_next) {
-#pragma unroll
-          for (int k = 0; k < kVecPerThread; ++k) {
-            rv[k] = rn[k];
-            dv[k] = dn[k];
-          }
-        }
-        have = have_next;
-        ch = ch1;
-        ch1 = ch2;
-      }
+    } else {
+      const int n4 = ch.len >> 2;
+      for (int i = tid; i < n4; i += kBlock) accumulate4<KIND>(r4[i], d4[i], a0, a1, a2);
+      const int tail = ch.len & 3;
+      if (tid < tail) accumulate<KIND>(r[(n4 << 2) + tid], d[(n4 << 2) + tid], b0, b1, b2);
     }
+    const double s0 = (double)a0 + (double)b0, s1 = (double)a1 + (double)b1, s2 = (double)a2 + (double)b2;
+    if constexpr (KIND == BH_GM_TAG) {
+      // objectives.py:139-140: (rec-data).pow(2).sum() + tag_scale * weight * (rec-data).abs().sum(), weight per tensor
+      acc[0] += s0 + (double)tag_scale * (double)weights[ch.tensor] * s1;
+    } else {
+      acc[0] += s0;
+    }
+    acc[1] += s1;
+    acc[2] += s2;
   }
   bh::block_sum<3>(acc, lds);
   if (tid == 0) {
@@ -436,26 +360,16 @@ struct LaunchEvents {
   hipEvent_t start = nullptr, stop = nullptr;
 };
 
-int g_fwd_pipeline = BH_GM_DEFAULT_PIPELINE;
-
 template <int KIND>
 void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_begin,
                 int chunk_end, int grid, const float* weights, float tag_scale, double* partials, int row_base,
                 hipStream_t st, LaunchEvents ev) {
-#define BH_GM_FWD_LAUNCH(PIPE)                                                                                          \
-  do {                                                                                                                  \
-    if (ev.start || ev.stop)                                                                                            \
-      hipExtLaunchKernelGGL((gm_fwd_kernel<KIND, PIPE>), dim3(grid), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs,   \
-                            tensor_base, data_flat, chunks, chunk_begin, chunk_end, weights, tag_scale, partials,       \
-                            row_base);                                                                                  \
-    else                                                                                                                \
-      hipLaunchKernelGGL((gm_fwd_kernel<KIND, PIPE>), dim3(grid), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat,    \
-                         chunks, chunk_begin, chunk_end, weights, tag_scale, partials, row_base);                       \
-  } while (0)
-  if (g_fwd_pipeline == 0) BH_GM_FWD_LAUNCH(0);
-  else if (g_fwd_pipeline == 1) BH_GM_FWD_LAUNCH(1);
-  else BH_GM_FWD_LAUNCH(2);
-#undef BH_GM_FWD_LAUNCH
+  if (ev.start || ev.stop)
+    hipExtLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
+                          data_flat, chunks, chunk_begin, chunk_end, weights, tag_scale, partials, row_base);
+  else
+    hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+                       chunk_begin, chunk_end, weights, tag_scale, partials, row_base);
 }
 
 template <int KIND>
@@ -616,12 +530,6 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
     if (rc != 0) return rc;
     row_base += grid;
   }
-  return 0;
-}
-
-int bh_gm_set_pipeline(int32_t mode) {
-  if (mode < 0 || mode > 2) return BH_EINVAL;
-  g_fwd_pipeline = mode;
   return 0;
 }
 

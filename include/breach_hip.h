@@ -113,11 +113,6 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
 int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin);
 /* Tuning knob (process global, host side): cap of workgroups per forward launch group, 1..BH_GM_MAX_ROWS. */
 int32_t bh_gm_set_rows_cap(int32_t cap);
-/* Tuning knob (process global, host side): software pipelining of the forward kernel's chunk loop -- 0: one chunk at a
- * time (round 2), 1: next chunk descriptor prefetched, 2: descriptors two ahead + the next full chunk's loads issued
- * before the current chunk is summed.  Results are bit-identical across modes. */
-#define BH_GM_DEFAULT_PIPELINE 2
-int bh_gm_set_pipeline(int32_t mode);
 /* `ev_start` / `ev_stop` (here and in bh_gm_bwd): optional hipEvent_t handles from bh_event_create.  When given, the
  * launch goes through hipExtLaunchKernelGGL, so the events carry the dispatch's own begin / end timestamps (the
  * completion-signal times rocprofv3 reports) -- no host latency, no marker overhead.  Not usable during stream

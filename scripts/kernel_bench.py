@@ -52,21 +52,6 @@ def gm_case(name, shapes):
         f, e, b = sum(fwd) / len(fwd), sum(fin) / len(fin), sum(bwd) / len(bwd)
         res[kind_name] = dict(fwd_us=round(f, 2), fwd_GBs=round(2 * n * 4 / f / 1e3, 1), finalize_us=round(e, 2),
                               stage_GBs=round(2 * n * 4 / (f + e) / 1e3, 1), bwd_us=round(b, 2), bwd_GBs=round(3 * n * 4 / b / 1e3, 1))
-    # software pipelining of the forward chunk loop (bh_gm_set_pipeline) x rows cap, cosine kind, ext-launch events
-    pipe = {}
-    for mode in (0, 1, 2):
-        lib.bh_gm_set_pipeline(mode)
-        for cap in (512, 1024):
-            lib.bh_gm_set_rows_cap(cap)
-            plan_p = GradientMatchPlan(data)
-            plan_p.enable_timing()
-            for _ in range(30):
-                plan_p.forward(_lib.GM_KINDS["cosine-similarity"], rec, 1.0, 0.1, 1e-7, None)
-            t = sorted(plan_p.drain_timers()["fwd"])[5:]
-            pipe[f"mode{mode}_rows{cap}"] = round(sum(t) / len(t), 2)
-    lib.bh_gm_set_pipeline(_lib.BH_GM_DEFAULT_PIPELINE)
-    lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
-    res["fwd_us_by_pipeline_mode"] = pipe
     # Forward launch right after a kernel REWROTE the whole reconstructed list (what autograd does in the loop): the producer's
     # dirty lines drain to HBM while kernel A streams -- the in-loop condition the warm figures above do not have.
     kind = _lib.GM_KINDS["cosine-similarity"]

@@ -558,32 +558,3 @@ def test_deepinversion_taps_accumulate_into_the_activation_gradient(kernels_orac
     (ggb,) = torch.autograd.grad((gb ** 2).sum(), xb)
     torch.testing.assert_close(ga, gb, rtol=0, atol=0)
     torch.testing.assert_close(gga, ggb, rtol=1e-6, atol=1e-9)
-
-
-def test_gm_forward_pipelining_modes_are_bit_identical(hip_lib):
-    """bh_gm_set_pipeline only changes WHEN a chunk's loads are issued (descriptor / data prefetch), never the arithmetic: the
-    partial rows and the finalized statistics are bit-identical in all three modes, for full, ragged and tiny tensors, more than
-    one chunk per workgroup (rows cap 8) included."""
-    from breaching_amd import _lib
-    from breaching_amd.gm import GradientMatchPlan
-
-    rng = np.random.default_rng(11)
-    shapes = [(4096 * 7 + 5,), (3,), (4096,), (4096 * 2,), (17, 33), (1,), (70_001,), (4096 * 3 - 1,)]
-    data = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
-    rec = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
-    weights = torch.linspace(1, 0.2, len(shapes), device=_dev())
-    try:
-        for cap in (8, _lib.BH_GM_DEFAULT_ROWS):
-            assert hip_lib.bh_gm_set_rows_cap(cap) == 0
-            for kind_name in ("cosine-similarity", "euclidean", "tag-euclidean", "masked-cosine-similarity", "l1"):
-                results = []
-                for mode in (0, 1, 2):
-                    assert hip_lib.bh_gm_set_pipeline(mode) == 0
-                    plan = GradientMatchPlan(data)
-                    stats = plan.forward(_lib.GM_KINDS[kind_name], rec, 0.7, 0.1, 1e-7, weights if kind_name == "tag-euclidean" else None)
-                    results.append(stats.cpu().numpy().view(np.uint32).copy())
-                assert np.array_equal(results[0][:6], results[1][:6]) and np.array_equal(results[0][:6], results[2][:6]), (cap, kind_name)
-        assert hip_lib.bh_gm_set_pipeline(3) == -1
-    finally:
-        hip_lib.bh_gm_set_pipeline(_lib.BH_GM_DEFAULT_PIPELINE)
-        hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
