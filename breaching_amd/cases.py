@@ -241,6 +241,35 @@ def build_case(model_name="convnet", data_name="CIFAR10", num_data_points=1, dev
                     true_user_data=dict(data=x_true, labels=labels), data_cfg=data_cfg)
 
 
+def build_multi_query_case(queries=2, device="cpu", num_data_points=2, seed_model=0, seed_data=1, drift=0.01):
+    """One user answering `queries` server queries (the reference's `num_queries`, servers.py:150-165 / users.py): the same
+    private batch, a different model state per query (query 0 = the seeded ConvNet, query q > 0 = its parameters moved by
+    seeded Gaussian noise of scale `drift`), one gradient list per query.  The attacker then sums the gradient-matching
+    objective over the (model, gradient) pairs (optimization_based_attack.py:152-155)."""
+    import copy
+
+    base = build_case("convnet", "CIFAR10", num_data_points, device="cpu", seed_model=seed_model, seed_data=seed_data)
+    x_true, labels = base.true_user_data["data"], base.true_user_data["labels"]
+    device = torch.device(device)
+    models, payloads, shared = [], [], []
+    gen = torch.Generator().manual_seed(1000 + seed_model)
+    for q in range(queries):
+        model = copy.deepcopy(base.model)
+        if q > 0:
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.add_(drift * torch.randn(p.shape, generator=gen))
+        entry = single_step_update(model, base.loss_fn, x_true, labels, True, False)[0]
+        entry["gradients"] = [g.to(device) for g in entry["gradients"]]
+        entry["metadata"]["labels"] = entry["metadata"]["labels"].to(device)
+        model = model.to(device)
+        models.append(model)
+        payloads.extend(honest_payload(model, base.data_cfg, public_buffers=True))
+        shared.append(entry)
+    return AttrDict(model=models[0].to(device), models=models, loss_fn=base.loss_fn, server_payload=payloads, shared_data=shared,
+                    true_user_data=dict(data=x_true, labels=labels), data_cfg=base.data_cfg)
+
+
 def psnr(reconstruction, truth, data_cfg):
     """Mean per-example PSNR on de-normalised, clamped images (analysis.py:228-229, metrics.py:122-130, factor=1)."""
     mean = torch.as_tensor(data_cfg.mean, dtype=torch.float32)[None, :, None, None]

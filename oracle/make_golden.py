@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz by running the UNMODIFIED reference in the build container.
 
-    python -m oracle.make_golden [--only configs|kernels|schedules|convnet|resnet18|seethrough|tag|variants|fedavg|labels|dlg|pearlmutter]
+    python -m oracle.make_golden [--only configs|kernels|schedules|convnet|resnet18|seethrough|tag|variants|fedavg|labels|dlg|multiquery|pearlmutter]
     python -m oracle.make_golden --only resnet18_long|seethrough_b8|tag_bert_base      (slow: run by name only)
 
 Needs /root/reference (through oracle/ref_shim.py); the outputs are committed so that the GPU box -- which has no
@@ -326,6 +326,30 @@ def golden_convnet():
     twins, twin_psnr, twin_opt = _twin_runs(cfg, case, x0, 2)
     out.update(l2soft_twin_history=twins, l2soft_twin_psnr=twin_psnr, l2soft_twin_opt_value=twin_opt)
     np.savez_compressed(os.path.join(GOLDEN, "attack_convnet.npz"), **out)
+
+
+def golden_multiquery():
+    """Two server queries answered by one user (two model states, two gradient lists): the objective is summed over the
+    (model, gradient) pairs (optimization_based_attack.py:152-155), one packed plan per list on the HIP side.  Smooth
+    configuration (euclidean, soft sign) so that the whole trajectory is comparable at 1e-4."""
+    from breaching_amd.cases import build_multi_query_case, initial_candidate
+
+    torch.set_num_threads(8)
+    case = build_multi_query_case(2)
+    cfg = _cfg("invertinggradients", ["objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft",
+                                      "optim.max_iterations=16", "restarts.scoring=euclidean", "optim.callback=8"])
+    x0 = initial_candidate(case.data_cfg, 2, seed=6)
+    rec, stats = _run_reference_attack(cfg, case, x0)
+    out = _attack_record(cfg, case, x0, rec, stats)
+    twins, twin_psnr, twin_opt = _twin_runs(cfg, case, x0, 2)
+    out.update(twin_history=twins, twin_psnr=twin_psnr, twin_opt_value=twin_opt,
+               grad1_checksum=np.float64(case.shared_data[1]["gradients"][0].double().sum()))
+    # one query alone must give a different trajectory: the fixture really exercises the sum over queries
+    single = type(case)(case)
+    single.server_payload, single.shared_data = case.server_payload[:1], case.shared_data[:1]
+    _, stats1 = _run_reference_attack(cfg, single, x0)
+    out["single_query_history"] = np.asarray(stats1["Trial_0_Val"], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLDEN, "attack_multiquery.npz"), **out)
 
 
 def golden_variants():
@@ -750,7 +774,7 @@ def golden_tag():
 
 STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_schedules, convnet=golden_convnet,
              resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
-             variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg,
+             variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg, multiquery=golden_multiquery,
              resnet18_long=golden_resnet18_long, seethrough_b8=golden_seethrough_b8, tag_bert_base=golden_tag_bert_base,
              pearlmutter=golden_pearlmutter)
 SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base")  # hours of CPU: only run when asked for by name

@@ -221,6 +221,23 @@ def test_attacker_vs_restatement_with_restarts():
     torch.testing.assert_close(rec["data"].cpu(), rec_o["data"], rtol=1e-3, atol=1e-3)
 
 
+def test_two_server_queries_sum_the_objective_over_models(golden_dir):
+    """`num_queries = 2` (two model states, two observed gradient lists of the same private batch): one packed plan per list,
+    the objective summed over the pairs (optimization_based_attack.py:152-155), against the unmodified reference's run."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_multi_query_case, initial_candidate
+
+    gold = np.load(os.path.join(golden_dir, "attack_multiquery.npz"))
+    case = build_multi_query_case(2, device="cuda:0")
+    cfg = get_attack_config("invertinggradients", ["objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft",
+                                                   "optim.max_iterations=16", "restarts.scoring=euclidean", "optim.callback=8"])
+    x0 = initial_candidate(case.data_cfg, 2, seed=6)
+    rec, stats, attacker = _attack(case, cfg, x0)
+    assert len(attacker.objective._plans) == 2 and stats["execution"]["trials"] == {0: "hipGraph replay"}
+    _check_against_golden("", gold, rec, stats, case)
+    assert not np.allclose(stats["Trial_0_Val"], gold["single_query_history"], rtol=1e-4)
+
+
 def test_random_restarts_select_the_best_trial():
     """Random initialisation, 3 trials: the returned candidate is the one with the smallest rescored objective."""
     from breaching_amd import get_attack_config
