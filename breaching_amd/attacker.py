@@ -332,8 +332,9 @@ class HipOptimizationAttacker:
                     buffer.copy_(server_state.to(**self.setup))
             if self.cfg.impl.JIT is not None:
                 raise NotImplementedError("impl.JIT (torch.jit script/trace of the victim model) is not supported.")
-            if fast_eval_bn_enabled(self.cfg):
-                use_affine_eval_batchnorm(new_model)
+            bn_mode = fast_eval_bn_mode(self.cfg)
+            if bn_mode is not None:
+                use_affine_eval_batchnorm(new_model, bn_mode)
             models.append(new_model)
         return models
 
@@ -855,18 +856,106 @@ DEFAULT_TRIALS_IN_FLIGHT = 4
 MAX_TRIALS_IN_FLIGHT = 4
 
 
+def _vector_ready(t, hw):
+    """Contiguous fp32, and 16-byte aligned when the kernels will use 16-byte accesses (H*W % 4 == 0)."""
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if hw % 4 == 0 and t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+class _EvalBNFunction(torch.autograd.Function):
+    """y = x * s_c + t_c of an eval-mode BatchNorm2d as ONE launch (bh_bn_eval_fwd); its backward is `_EvalBNGradFunction`, one
+    launch again and itself differentiable -- the attack needs the derivative of the first-order pass (objectives.py:40-46
+    under create_graph=True, then optimization_based_attack.py:160)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, inv_std, mean_inv):
+        lib = _lib.load()
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        xk = _vector_ready(x.detach(), hw)
+        y = torch.empty_like(xk)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bh_bn_eval_fwd(_lib.ptr(xk), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(inv_std), _lib.ptr(mean_inv),
+                                          _lib.ptr(y), B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_fwd")
+        # the INPUT itself is saved (not the detached kernel view): the backward below is differentiable with respect to it
+        ctx.save_for_backward(x, weight, inv_std, mean_inv)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, inv_std, mean_inv = ctx.saved_tensors
+        gx, gw, gb = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv)
+        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None
+
+
+class _EvalBNGradFunction(torch.autograd.Function):
+    """(gy, x, weight) -> (gx, gw, gb) in one launch (bh_bn_eval_bwd); backward = the derivative of that map in one launch
+    (bh_bn_eval_bwd_bwd).  PyTorch's decomposition of the same three orders is ~35 launches per layer."""
+
+    @staticmethod
+    def forward(ctx, gy, x, weight, inv_std, mean_inv):
+        lib = _lib.load()
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        gyk = _vector_ready(gy.detach().to(torch.float32), hw)
+        xk = _vector_ready(x.detach(), hw)
+        gx = torch.empty_like(xk)
+        gw = torch.empty(C, dtype=torch.float32, device=x.device)
+        gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bh_bn_eval_bwd(_lib.ptr(gyk), _lib.ptr(xk), _lib.ptr(weight), _lib.ptr(inv_std), _lib.ptr(mean_inv),
+                                          _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), B, C, hw,
+                                          _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd")
+        ctx.save_for_backward(gyk, xk, weight, inv_std, mean_inv)
+        ctx.set_materialize_grads(False)
+        return gx, gw, gb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, ggx, ggw, ggb):
+        lib = _lib.load()
+        gy, x, weight, inv_std, mean_inv = ctx.saved_tensors
+        if ggx is None and ggw is None and ggb is None:
+            return None, None, None, None, None
+        B, C = x.shape[0], x.shape[1]
+        hw = x[0, 0].numel()
+        ggx = None if ggx is None else ggx.to(torch.float32).contiguous()
+        ggw = None if ggw is None else ggw.to(torch.float32).contiguous()
+        ggb = None if ggb is None else ggb.to(torch.float32).contiguous()
+        d_gy = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d_x = torch.empty_like(x) if (ctx.needs_input_grad[1] and ggw is not None) else None
+        d_w = torch.empty(C, dtype=torch.float32, device=x.device) if (weight is not None and ctx.needs_input_grad[2] and ggx is not None) else None
+        if d_gy is None and d_x is None and d_w is None:
+            return None, None, None, None, None
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bh_bn_eval_bwd_bwd(_lib.ptr(ggx), _lib.ptr(ggw), _lib.ptr(ggb), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight),
+                                              _lib.ptr(inv_std), _lib.ptr(mean_inv), _lib.ptr(d_gy), _lib.ptr(d_x), _lib.ptr(d_w),
+                                              B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd_bwd")
+        return d_gy, d_x, d_w, None, None
+
+
 class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
-    """BatchNorm2d whose inference-mode forward is written as one broadcast multiply-add.
+    """BatchNorm2d whose inference-mode forward is the per-channel affine map it is: ``y = x * s + t`` with
+    ``s = w / sqrt(var + eps)``, ``t = b - mean * s``.
 
     Same parameters, buffers, hooks and ``isinstance`` behaviour as ``torch.nn.BatchNorm2d`` (instances are converted by
-    swapping ``__class__``); only the op sequence differs: ``y = x * s + t`` with ``s = w / sqrt(var + eps)``,
-    ``t = b - mean * s``.  PyTorch's double backward of ``F.batch_norm`` in eval mode decomposes into ~25 small kernels
-    per layer per iteration; this formulation needs a handful.  Training-mode batches fall through to the stock path."""
+    swapping ``__class__``); only the op sequence differs.  PyTorch's double backward of ``F.batch_norm`` in eval mode
+    decomposes into dozens of small kernels per layer per iteration.  Mode "hip" (default): one HIP launch per autograd order
+    (`_EvalBNFunction`); mode "addcmul" (round 2): one broadcast multiply-add in torch ops, autograd decomposes the rest.
+    Training-mode batches, non-4-D, non-fp32 or non-ROCm inputs fall through to the stock / torch path."""
+
+    eval_mode = "hip"
 
     def forward(self, x):
         if self.training or self.running_mean is None or self.running_var is None or x.dim() != 4:
             return super().forward(x)
         inv_std, mean_inv = self._frozen_statistics()
+        if self.eval_mode == "hip" and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:
+            return _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv)
         if self.weight is not None:
             scale = self.weight * inv_std
             shift = -(self.weight * mean_inv)
@@ -883,29 +972,42 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
         cached = getattr(self, "_frozen", None)
         if cached is None or cached[0] != key:
             with torch.no_grad():
-                inv_std = torch.rsqrt(self.running_var + self.eps)
-                cached = (key, inv_std, self.running_mean * inv_std)
+                inv_std = torch.rsqrt(self.running_var + self.eps).to(torch.float32).contiguous()
+                cached = (key, inv_std, (self.running_mean * inv_std).to(torch.float32).contiguous())
             self._frozen = cached
         return cached[1], cached[2]
 
 
-def use_affine_eval_batchnorm(model):
-    """Convert every plain BatchNorm2d of `model` in place (idempotent).  On by default; cfg.impl.fast_eval_bn=False or
-    BREACH_HIP_FAST_BN=0 keeps the stock modules."""
+def use_affine_eval_batchnorm(model, mode="hip"):
+    """Convert every plain BatchNorm2d of `model` in place (idempotent).  On by default; cfg.impl.fast_eval_bn (True / "hip" /
+    "addcmul" / False) or BREACH_HIP_FAST_BN (1 / hip / addcmul / 0) choose the formulation or keep the stock modules."""
     for module in model.modules():
         if type(module) is torch.nn.BatchNorm2d:
             module.__class__ = _EvalAffineBatchNorm2d
+        if type(module) is _EvalAffineBatchNorm2d:
+            module.eval_mode = mode
     return model
 
 
-def fast_eval_bn_enabled(cfg):
+def fast_eval_bn_mode(cfg):
+    """"hip" (default), "addcmul" or None (stock modules)."""
     import os
 
-    env = os.environ.get("BREACH_HIP_FAST_BN")
-    if env is not None:
-        return env != "0"
-    flag = _cfg_get(cfg.impl, "fast_eval_bn", True)
-    return True if flag is None else bool(flag)
+    flag = os.environ.get("BREACH_HIP_FAST_BN")
+    if flag is None:
+        flag = _cfg_get(cfg.impl, "fast_eval_bn", True)
+    if flag is None or flag is True:
+        return "hip"
+    if flag is False:
+        return None
+    flag = str(flag).strip().lower()
+    if flag in ("0", "false", "off", "no", "stock"):
+        return None
+    return "addcmul" if flag == "addcmul" else "hip"
+
+
+def fast_eval_bn_enabled(cfg):
+    return fast_eval_bn_mode(cfg) is not None
 
 
 def trials_in_flight(cfg):

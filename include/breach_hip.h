@@ -254,6 +254,26 @@ int bh_bn_bwd_accumulate(const float* x, const float* gin, int32_t hw, const bh_
                          float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Eval-mode BatchNorm of the attacker's private model copy, one launch per autograd order.
+ * reference: base_attack.py:176-212 rebuilds the victim model and puts it in eval() whenever buffers are known; its
+ * BatchNorm2d layers are then the per-channel affine map y = x * s_c + t_c (s_c = weight_c * inv_std_c,
+ * t_c = bias_c - weight_c * mean_inv_c, inv_std = 1/sqrt(running_var + eps), mean_inv = running_mean * inv_std), which the
+ * attack differentiates twice per iteration (objectives.py:40-46 with create_graph=True, optimization_based_attack.py:160).
+ * x / y / gradients: [B, C, HW] contiguous fp32 (16-byte aligned when HW % 4 == 0); weight / bias may be NULL (affine=False);
+ * per-channel sums in fp64, fixed order.  No allocation, no synchronisation. */
+int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* inv_std, const float* mean_inv, float* y,
+                   int32_t B, int32_t C, int32_t HW, void* stream);
+/* gx = gy * s_c (skipped when gx is NULL); gw_c = inv_std_c * sum(gy * x) - mean_inv_c * sum(gy); gb_c = sum(gy). */
+int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
+                   float* gw, float* gb, int32_t B, int32_t C, int32_t HW, void* stream);
+/* Derivative of bh_bn_eval_bwd for incoming (ggx [B,C,HW], ggw [C], ggb [C]; each may be NULL = zero):
+ * d_gy = ggx * s_c + ggw_c * (inv_std_c * x - mean_inv_c) + ggb_c;  d_x = ggw_c * inv_std_c * gy;  d_w_c = inv_std_c * sum(ggx * gy).
+ * Outputs may be NULL (not computed). */
+int bh_bn_eval_bwd_bwd(const float* ggx, const float* ggw, const float* ggb, const float* gy, const float* x, const float* weight,
+                       const float* inv_std, const float* mean_inv, float* d_gy, float* d_x, float* d_w, int32_t B, int32_t C,
+                       int32_t HW, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Multi-tensor elementwise kernels over per-parameter lists (FedAvg unroll, Pearlmutter offset) and batch kernels
  * ---------------------------------------------------------------------------------------------------------------- */
 

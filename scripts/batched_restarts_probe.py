@@ -26,7 +26,7 @@ args = p.parse_args()
 dev = torch.device(args.device)
 on_gpu = dev.type == "cuda"
 case = build_case(args.model, args.data, 1, device=dev, gradient_device=dev if on_gpu else None) if on_gpu else build_case(args.model, args.data, 1, device=dev)
-model = use_affine_eval_batchnorm(case.model.to(dev).eval())
+model = use_affine_eval_batchnorm(case.model.to(dev).eval(), "addcmul")  # torch ops only: vmap has no rule for the HIP function
 params = {k: v.detach() for k, v in model.named_parameters()}
 buffers = {k: v.detach() for k, v in model.named_buffers()}
 names = list(params)

@@ -558,3 +558,55 @@ def test_deepinversion_taps_accumulate_into_the_activation_gradient(kernels_orac
     (ggb,) = torch.autograd.grad((gb ** 2).sum(), xb)
     torch.testing.assert_close(ga, gb, rtol=0, atol=0)
     torch.testing.assert_close(gga, ggb, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape,affine", [((1, 64, 112, 112), True), ((2, 12, 7, 7), True), ((3, 5, 9, 11), True), ((1, 512, 7, 7), True),
+                                          ((2, 6, 16, 16), False)])
+def test_eval_batchnorm_function_matches_torch_through_two_orders(shape, affine, hip_lib):
+    """The fused eval-mode BatchNorm (`_EvalBNFunction`: one launch forward, one for (gx, gw, gb), one for the derivative of
+    that) against PyTorch's own eval-mode `F.batch_norm` in fp64 on the CPU -- the arithmetic the reference runs -- through
+    both autograd orders the attack uses: y; d/d(x, w, b) of a scalar of y under create_graph; and the gradient of a scalar
+    of THOSE with respect to x (the path from the gradient-matching objective back to the candidate) and w."""
+    from breaching_amd.attacker import _EvalAffineBatchNorm2d, use_affine_eval_batchnorm
+
+    torch.manual_seed(sum(shape))
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C, affine=affine).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.4, 2.0)
+        if affine:
+            bn.weight.normal_(1.0, 0.3)
+            bn.bias.normal_(0, 0.2)
+    x_cpu = torch.randn(shape, dtype=torch.float64)
+    mix1, mix2 = torch.randn(shape, dtype=torch.float64), torch.randn(shape, dtype=torch.float64)
+    mw, mb = torch.randn(C, dtype=torch.float64), torch.randn(C, dtype=torch.float64)
+
+    def run(module, x, cast):
+        x = x.clone().requires_grad_(True)
+        params = [p for p in module.parameters()]
+        y = module(x)
+        first = torch.autograd.grad((y * y * cast(mix1)).sum(), [x, *params], create_graph=True)  # gy = 2 y mix1 depends on x
+        scalar = (first[0] * cast(mix2)).sum()
+        if params:
+            scalar = scalar + (first[1] * cast(mw)).sum() + (first[2] * cast(mb)).sum()
+        second = torch.autograd.grad(scalar, [x, *params[:1]], allow_unused=True)
+        return y.detach(), [f.detach() for f in first], [None if g is None else g.detach() for g in second]
+
+    import copy
+    ref = run(copy.deepcopy(bn).double(), x_cpu, lambda t: t)
+    hip_bn = use_affine_eval_batchnorm(copy.deepcopy(bn).to(_dev()), "hip")
+    assert type(hip_bn) is _EvalAffineBatchNorm2d and hip_bn.eval_mode == "hip"
+    got = run(hip_bn, x_cpu.to(_dev(), torch.float32), lambda t: t.to(_dev(), torch.float32))
+
+    def close(a, b, what):
+        a, b = a.cpu().double().numpy(), b.numpy()
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err <= 2e-5, (what, err)
+
+    close(got[0], ref[0], "y")
+    for k, name in enumerate(["gx", "gw", "gb"][: len(ref[1])]):
+        close(got[1][k], ref[1][k], name)
+    close(got[2][0], ref[2][0], "second order wrt x")
+    if affine:
+        close(got[2][1], ref[2][1], "second order wrt weight")
