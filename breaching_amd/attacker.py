@@ -906,9 +906,11 @@ class _EvalBNGradFunction(torch.autograd.Function):
         gx = torch.empty_like(xk)
         gw = torch.empty(C, dtype=torch.float32, device=x.device)
         gb = torch.empty(C, dtype=torch.float32, device=x.device)
+        slabs = lib.bh_bn_eval_slabs(B, C, hw)
+        ws = torch.empty(2 * C * slabs, dtype=torch.float64, device=x.device) if slabs > 1 else None
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_bwd(_lib.ptr(gyk), _lib.ptr(xk), _lib.ptr(weight), _lib.ptr(inv_std), _lib.ptr(mean_inv),
-                                          _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), B, C, hw,
+                                          _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), B, C, hw,
                                           _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd")
         ctx.save_for_backward(gyk, xk, weight, inv_std, mean_inv)
         ctx.set_materialize_grads(False)
@@ -931,10 +933,14 @@ class _EvalBNGradFunction(torch.autograd.Function):
         d_w = torch.empty(C, dtype=torch.float32, device=x.device) if (weight is not None and ctx.needs_input_grad[2] and ggx is not None) else None
         if d_gy is None and d_x is None and d_w is None:
             return None, None, None, None, None
+        if ggx is not None and hw % 4 == 0 and ggx.data_ptr() % 16:
+            ggx = ggx.clone()
+        slabs = lib.bh_bn_eval_slabs(B, C, hw)
+        ws = torch.empty(C * slabs, dtype=torch.float64, device=x.device) if slabs > 1 else None
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_bwd_bwd(_lib.ptr(ggx), _lib.ptr(ggw), _lib.ptr(ggb), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight),
                                               _lib.ptr(inv_std), _lib.ptr(mean_inv), _lib.ptr(d_gy), _lib.ptr(d_x), _lib.ptr(d_w),
-                                              B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd_bwd")
+                                              _lib.ptr(ws), B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd_bwd")
         return d_gy, d_x, d_w, None, None
 
 

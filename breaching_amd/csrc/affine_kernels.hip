@@ -21,23 +21,30 @@ namespace {
 
 using bh::kBlock;
 
-// Geometry shared by the three kernels: x is [B, C, HW] contiguous.  Wide: workgroup blockIdx.x owns channel blockIdx.x; narrow
-// (B * HW <= kNarrow): one wavefront per channel, four channels per workgroup.
+// Geometry shared by the three kernels: x is [B, C, HW] contiguous; the B planes of a channel form one virtual array of
+// B * HW elements.  Narrow (B * HW <= kNarrow): one wavefront per channel, four channels per workgroup.  Otherwise a channel
+// is cut into S slabs of about kSlabTarget elements, one workgroup each (S = 1 for every ResNet-18 layer at B = 1: the whole
+// order is one launch); with S > 1 the per-slab channel sums go to a workspace and a small second launch finishes them --
+// large activations (ResNet-50 at B = 8: up to 100 k elements per channel) would otherwise be streamed by C workgroups only.
 constexpr int kNarrow = 512;
+constexpr int kSlabTarget = 16384;
+constexpr int kMaxSlabs = 64;
 
 struct ChannelWalk {
-  int c, lane, lanes;
+  int c, slab, lane, lanes;
   bool active;
 };
 
-__device__ __forceinline__ ChannelWalk channel_of(int C, bool narrow) {
+__device__ __forceinline__ ChannelWalk channel_of(int C, int S, bool narrow) {
   ChannelWalk w;
   if (narrow) {
     w.c = blockIdx.x * bh::kWavesPerBlock + (threadIdx.x >> 6);
+    w.slab = 0;
     w.lane = threadIdx.x & (bh::kWave - 1);
     w.lanes = bh::kWave;
   } else {
-    w.c = blockIdx.x;
+    w.c = blockIdx.x / S;
+    w.slab = blockIdx.x - w.c * S;
     w.lane = threadIdx.x;
     w.lanes = kBlock;
   }
@@ -45,7 +52,15 @@ __device__ __forceinline__ ChannelWalk channel_of(int C, bool narrow) {
   return w;
 }
 
-// per-channel sums of K doubles: wide = block_sum, narrow = wave_sum; result valid in lane 0 of the owner
+// the slab's range [v0, v1) of the channel's virtual array, in units (float4 when HW % 4 == 0, float otherwise)
+__device__ __forceinline__ void slab_range(int B, int HW, int S, int slab, bool vec, uint32_t& unit, uint32_t& v0, uint32_t& v1) {
+  unit = vec ? (uint32_t)(HW >> 2) : (uint32_t)HW;
+  const uint32_t total = (uint32_t)B * unit;
+  v0 = (uint32_t)((uint64_t)total * (uint32_t)slab / (uint32_t)S);
+  v1 = (uint32_t)((uint64_t)total * ((uint32_t)slab + 1u) / (uint32_t)S);
+}
+
+// per-channel(-slab) sums of K doubles: wide = block_sum, narrow = wave_sum; result valid in lane 0 of the owner
 template <int K>
 __device__ __forceinline__ void channel_sum(double (&v)[K], bool narrow, double* lds) {
   if (narrow) {
@@ -59,82 +74,83 @@ __device__ __forceinline__ void channel_sum(double (&v)[K], bool narrow, double*
 __global__ __launch_bounds__(kBlock) void bn_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                              const float* __restrict__ bias, const float* __restrict__ inv_std,
                                                              const float* __restrict__ mean_inv, float* __restrict__ y, int B,
-                                                             int C, int HW, int narrow) {
-  const ChannelWalk w = channel_of(C, narrow != 0);
+                                                             int C, int HW, int S, int narrow) {
+  const ChannelWalk w = channel_of(C, S, narrow != 0);
   if (!w.active) return;
   const float wc = weight ? weight[w.c] : 1.f;
   const float s = wc * inv_std[w.c];
   const float t = (bias ? bias[w.c] : 0.f) - wc * mean_inv[w.c];
-  for (int b = 0; b < B; ++b) {
-    const size_t base = ((size_t)b * C + w.c) * HW;
-    if ((HW & 3) == 0) {
-      const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + base);
-      float4* __restrict__ y4 = reinterpret_cast<float4*>(y + base);
-      for (int i = w.lane; i < (HW >> 2); i += w.lanes) {
-        const float4 q = x4[i];
-        y4[i] = make_float4(fmaf(q.x, s, t), fmaf(q.y, s, t), fmaf(q.z, s, t), fmaf(q.w, s, t));
-      }
+  const bool vec = (HW & 3) == 0;
+  uint32_t unit, v0, v1;
+  slab_range(B, HW, S, w.slab, vec, unit, v0, v1);
+  const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
+  for (uint32_t v = v0 + (uint32_t)w.lane; v < v1; v += (uint32_t)w.lanes) {
+    const uint32_t b = B == 1 ? 0u : v / unit, j = v - b * unit;
+    const size_t at = (size_t)b * cstride + cbase + j;
+    if (vec) {
+      const float4 q = reinterpret_cast<const float4*>(x)[at];
+      reinterpret_cast<float4*>(y)[at] = make_float4(fmaf(q.x, s, t), fmaf(q.y, s, t), fmaf(q.z, s, t), fmaf(q.w, s, t));
     } else {
-      for (int i = w.lane; i < HW; i += w.lanes) y[base + i] = fmaf(x[base + i], s, t);
+      y[at] = fmaf(x[at], s, t);
     }
   }
 }
 
+// partial layout when S > 1: part[(c * S + slab) * 2 + k]
 __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                              const float* __restrict__ weight, const float* __restrict__ inv_std,
                                                              const float* __restrict__ mean_inv, float* __restrict__ gx,
-                                                             float* __restrict__ gw, float* __restrict__ gb, int B, int C, int HW,
-                                                             int narrow) {
+                                                             float* __restrict__ gw, float* __restrict__ gb,
+                                                             double* __restrict__ part, int B, int C, int HW, int S, int narrow) {
   __shared__ double lds[bh::kWavesPerBlock * 2];
-  const ChannelWalk w = channel_of(C, narrow != 0);
+  const ChannelWalk w = channel_of(C, S, narrow != 0);
   double v[2] = {0.0, 0.0};  // sum gy, sum gy * x
   if (w.active) {
     const float s = (weight ? weight[w.c] : 1.f) * inv_std[w.c];
-    for (int b = 0; b < B; ++b) {
-      const size_t base = ((size_t)b * C + w.c) * HW;
-      float a0 = 0.f, a1 = 0.f;
-      int cnt = 0;
-      if ((HW & 3) == 0) {
-        const float4* __restrict__ g4 = reinterpret_cast<const float4*>(gy + base);
-        const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x + base);
-        float4* __restrict__ o4 = reinterpret_cast<float4*>(gx + base);
-        for (int i = w.lane; i < (HW >> 2); i += w.lanes) {
-          const float4 g = g4[i], q = x4[i];
-          if (gx) o4[i] = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
-          a0 += (g.x + g.y) + (g.z + g.w);
-          a1 = fmaf(g.x, q.x, a1);
-          a1 = fmaf(g.y, q.y, a1);
-          a1 = fmaf(g.z, q.z, a1);
-          a1 = fmaf(g.w, q.w, a1);
-          if (++cnt == 8) {  // at most 32 values per fp32 accumulator
-            v[0] += (double)a0;
-            v[1] += (double)a1;
-            a0 = a1 = 0.f;
-            cnt = 0;
-          }
-        }
+    const bool vec = (HW & 3) == 0;
+    uint32_t unit, v0, v1;
+    slab_range(B, HW, S, w.slab, vec, unit, v0, v1);
+    const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
+    float a0 = 0.f, a1 = 0.f;
+    int cnt = 0;
+    for (uint32_t u = v0 + (uint32_t)w.lane; u < v1; u += (uint32_t)w.lanes) {
+      const uint32_t b = B == 1 ? 0u : u / unit, j = u - b * unit;
+      const size_t at = (size_t)b * cstride + cbase + j;
+      if (vec) {
+        const float4 g = reinterpret_cast<const float4*>(gy)[at], q = reinterpret_cast<const float4*>(x)[at];
+        if (gx) reinterpret_cast<float4*>(gx)[at] = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+        a0 += (g.x + g.y) + (g.z + g.w);
+        a1 = fmaf(g.x, q.x, a1);
+        a1 = fmaf(g.y, q.y, a1);
+        a1 = fmaf(g.z, q.z, a1);
+        a1 = fmaf(g.w, q.w, a1);
+        cnt += 4;
       } else {
-        for (int i = w.lane; i < HW; i += w.lanes) {
-          const float g = gy[base + i];
-          if (gx) gx[base + i] = g * s;
-          a0 += g;
-          a1 = fmaf(g, x[base + i], a1);
-          if (++cnt == 32) {
-            v[0] += (double)a0;
-            v[1] += (double)a1;
-            a0 = a1 = 0.f;
-            cnt = 0;
-          }
-        }
+        const float g = gy[at];
+        if (gx) gx[at] = g * s;
+        a0 += g;
+        a1 = fmaf(g, x[at], a1);
+        cnt += 1;
       }
-      v[0] += (double)a0;
-      v[1] += (double)a1;
+      if (cnt >= 32) {  // at most 32 values per fp32 accumulator
+        v[0] += (double)a0;
+        v[1] += (double)a1;
+        a0 = a1 = 0.f;
+        cnt = 0;
+      }
     }
+    v[0] += (double)a0;
+    v[1] += (double)a1;
   }
   channel_sum<2>(v, narrow != 0, lds);
   if (w.active && w.lane == 0) {
-    if (gw) gw[w.c] = (float)((double)inv_std[w.c] * v[1] - (double)mean_inv[w.c] * v[0]);
-    if (gb) gb[w.c] = (float)v[0];
+    if (S > 1) {
+      part[((size_t)w.c * S + w.slab) * 2] = v[0];
+      part[((size_t)w.c * S + w.slab) * 2 + 1] = v[1];
+    } else {
+      if (gw) gw[w.c] = (float)((double)inv_std[w.c] * v[1] - (double)mean_inv[w.c] * v[0]);
+      if (gb) gb[w.c] = (float)v[0];
+    }
   }
 }
 
@@ -143,86 +159,159 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
                                                                  const float* __restrict__ x, const float* __restrict__ weight,
                                                                  const float* __restrict__ inv_std,
                                                                  const float* __restrict__ mean_inv, float* __restrict__ d_gy,
-                                                                 float* __restrict__ d_x, float* __restrict__ d_w, int B, int C,
-                                                                 int HW, int narrow) {
+                                                                 float* __restrict__ d_x, float* __restrict__ d_w,
+                                                                 double* __restrict__ part, int B, int C, int HW, int S,
+                                                                 int narrow) {
   __shared__ double lds[bh::kWavesPerBlock];
-  const ChannelWalk w = channel_of(C, narrow != 0);
+  const ChannelWalk w = channel_of(C, S, narrow != 0);
   double v[1] = {0.0};  // sum ggx * gy
   if (w.active) {
     const float inv = inv_std[w.c], mi = mean_inv[w.c];
     const float s = (weight ? weight[w.c] : 1.f) * inv;
-    const float kw = ggw ? ggw[w.c] : 0.f;       // d objective / d gw_c
-    const float kb = ggb ? ggb[w.c] : 0.f;       // d objective / d gb_c
+    const float kw = ggw ? ggw[w.c] : 0.f;             // d objective / d gw_c
+    const float kb = ggb ? ggb[w.c] : 0.f;             // d objective / d gb_c
     const float kwi = kw * inv, shift = kb - kw * mi;  // d_gy = ggx * s + kwi * x + shift ;  d_x = kwi * gy
-    for (int b = 0; b < B; ++b) {
-      const size_t base = ((size_t)b * C + w.c) * HW;
-      float a0 = 0.f;
-      int cnt = 0;
-      for (int i = w.lane; i < HW; i += w.lanes) {
-        const float g = gy[base + i];
-        const float q = ggx ? ggx[base + i] : 0.f;
-        if (d_gy) d_gy[base + i] = fmaf(q, s, fmaf(kwi, x[base + i], shift));
-        if (d_x) d_x[base + i] = kwi * g;
-        a0 = fmaf(q, g, a0);
-        if (++cnt == 32) {
-          v[0] += (double)a0;
-          a0 = 0.f;
-          cnt = 0;
+    const bool vec = (HW & 3) == 0;
+    uint32_t unit, v0, v1;
+    slab_range(B, HW, S, w.slab, vec, unit, v0, v1);
+    const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
+    float a0 = 0.f;
+    int cnt = 0;
+    for (uint32_t u = v0 + (uint32_t)w.lane; u < v1; u += (uint32_t)w.lanes) {
+      const uint32_t b = B == 1 ? 0u : u / unit, j = u - b * unit;
+      const size_t at = (size_t)b * cstride + cbase + j;
+      if (vec) {
+        const float4 g = reinterpret_cast<const float4*>(gy)[at];
+        const float4 q = ggx ? reinterpret_cast<const float4*>(ggx)[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d_gy) {
+          const float4 xv = reinterpret_cast<const float4*>(x)[at];
+          reinterpret_cast<float4*>(d_gy)[at] = make_float4(fmaf(q.x, s, fmaf(kwi, xv.x, shift)), fmaf(q.y, s, fmaf(kwi, xv.y, shift)),
+                                                            fmaf(q.z, s, fmaf(kwi, xv.z, shift)), fmaf(q.w, s, fmaf(kwi, xv.w, shift)));
         }
+        if (d_x) reinterpret_cast<float4*>(d_x)[at] = make_float4(kwi * g.x, kwi * g.y, kwi * g.z, kwi * g.w);
+        a0 = fmaf(q.x, g.x, a0);
+        a0 = fmaf(q.y, g.y, a0);
+        a0 = fmaf(q.z, g.z, a0);
+        a0 = fmaf(q.w, g.w, a0);
+        cnt += 4;
+      } else {
+        const float g = gy[at];
+        const float q = ggx ? ggx[at] : 0.f;
+        if (d_gy) d_gy[at] = fmaf(q, s, fmaf(kwi, x[at], shift));
+        if (d_x) d_x[at] = kwi * g;
+        a0 = fmaf(q, g, a0);
+        cnt += 1;
       }
-      v[0] += (double)a0;
+      if (cnt >= 32) {
+        v[0] += (double)a0;
+        a0 = 0.f;
+        cnt = 0;
+      }
     }
+    v[0] += (double)a0;
   }
   channel_sum<1>(v, narrow != 0, lds);
-  if (w.active && w.lane == 0 && d_w) d_w[w.c] = (float)((double)inv_std[w.c] * v[0]);
+  if (w.active && w.lane == 0) {
+    if (S > 1) part[(size_t)w.c * S + w.slab] = v[0];
+    else if (d_w) d_w[w.c] = (float)((double)inv_std[w.c] * v[0]);
+  }
+}
+
+// Second stage when a channel was cut into S > 1 slabs: thread c adds its channel's S partial rows in slab order.
+// K = 2: (gw, gb) of the backward; K = 1: d_w of its derivative.
+template <int K>
+__global__ __launch_bounds__(kBlock) void bn_eval_combine_kernel(const double* __restrict__ part, const float* __restrict__ inv_std,
+                                                                 const float* __restrict__ mean_inv, float* __restrict__ out0,
+                                                                 float* __restrict__ out1, int C, int S) {
+  const int c = blockIdx.x * kBlock + threadIdx.x;
+  if (c >= C) return;
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = 0.0;
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += part[((size_t)c * S + s) * K + k];
+  }
+  if constexpr (K == 2) {
+    if (out0) out0[c] = (float)((double)inv_std[c] * v[1] - (double)mean_inv[c] * v[0]);  // gw
+    if (out1) out1[c] = (float)v[0];                                                        // gb
+  } else {
+    if (out0) out0[c] = (float)((double)inv_std[c] * v[0]);  // d_w
+  }
 }
 
 bool eval_bn_args_ok(const void* x, const void* inv_std, const void* mean_inv, int32_t B, int32_t C, int32_t HW) {
   return x != nullptr && inv_std != nullptr && mean_inv != nullptr && B > 0 && C > 0 && HW > 0 &&
-         (int64_t)B * C * HW < ((int64_t)1 << 40);
+         (int64_t)B * HW < ((int64_t)1 << 31) && (int64_t)B * C * HW < ((int64_t)1 << 40);
 }
 
-int eval_bn_grid(int32_t B, int32_t C, int32_t HW, int& narrow) {
-  narrow = ((int64_t)B * HW <= kNarrow) ? 1 : 0;
-  return narrow ? (C + bh::kWavesPerBlock - 1) / bh::kWavesPerBlock : C;
+int eval_bn_grid(int32_t B, int32_t C, int32_t HW, int& S, int& narrow) {
+  const int64_t per_channel = (int64_t)B * HW;
+  narrow = per_channel <= kNarrow ? 1 : 0;
+  S = 1;
+  if (!narrow) {
+    int64_t s = (per_channel + kSlabTarget / 2) / kSlabTarget;
+    S = (int)(s < 1 ? 1 : (s > kMaxSlabs ? kMaxSlabs : s));
+  }
+  return narrow ? (C + bh::kWavesPerBlock - 1) / bh::kWavesPerBlock : C * S;
 }
 
 }  // namespace
 
 extern "C" {
 
+int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW) {
+  if (B <= 0 || C <= 0 || HW <= 0) return BH_EINVAL;
+  int S = 1, narrow = 0;
+  eval_bn_grid(B, C, HW, S, narrow);
+  return S;
+}
+
 int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* inv_std, const float* mean_inv, float* y,
                    int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || y == nullptr) return BH_EINVAL;
   if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) != 0) return BH_EINVAL;
-  int narrow = 0;
-  const int grid = eval_bn_grid(B, C, HW, narrow);
+  int S = 1, narrow = 0;
+  const int grid = eval_bn_grid(B, C, HW, S, narrow);
   hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3(grid), dim3(kBlock), 0, bh::as_stream(stream), x, weight, bias, inv_std, mean_inv,
-                     y, B, C, HW, narrow);
+                     y, B, C, HW, S, narrow);
   return bh::launch_status();
 }
 
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
-                   float* gw, float* gb, int32_t B, int32_t C, int32_t HW, void* stream) {
+                   float* gw, float* gb, double* workspace, int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || gy == nullptr) return BH_EINVAL;
   if ((HW & 3) == 0 &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15u) != 0)
     return BH_EINVAL;
-  int narrow = 0;
-  const int grid = eval_bn_grid(B, C, HW, narrow);
-  hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(grid), dim3(kBlock), 0, bh::as_stream(stream), gy, x, weight, inv_std, mean_inv, gx,
-                     gw, gb, B, C, HW, narrow);
+  int S = 1, narrow = 0;
+  const int grid = eval_bn_grid(B, C, HW, S, narrow);
+  if (S > 1 && workspace == nullptr) return BH_EINVAL;
+  hipStream_t st = bh::as_stream(stream);
+  hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, gy, x, weight, inv_std, mean_inv, gx, gw, gb, workspace,
+                     B, C, HW, S, narrow);
+  if (S > 1 && (gw != nullptr || gb != nullptr))
+    hipLaunchKernelGGL(bn_eval_combine_kernel<2>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, workspace, inv_std,
+                       mean_inv, gw, gb, C, S);
   return bh::launch_status();
 }
 
 int bh_bn_eval_bwd_bwd(const float* ggx, const float* ggw, const float* ggb, const float* gy, const float* x, const float* weight,
-                       const float* inv_std, const float* mean_inv, float* d_gy, float* d_x, float* d_w, int32_t B, int32_t C,
-                       int32_t HW, void* stream) {
+                       const float* inv_std, const float* mean_inv, float* d_gy, float* d_x, float* d_w, double* workspace,
+                       int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || gy == nullptr) return BH_EINVAL;
-  int narrow = 0;
-  const int grid = eval_bn_grid(B, C, HW, narrow);
-  hipLaunchKernelGGL(bn_eval_bwd_bwd_kernel, dim3(grid), dim3(kBlock), 0, bh::as_stream(stream), ggx, ggw, ggb, gy, x, weight,
-                     inv_std, mean_inv, d_gy, d_x, d_w, B, C, HW, narrow);
+  if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(ggx) |
+                         reinterpret_cast<uintptr_t>(d_gy) | reinterpret_cast<uintptr_t>(d_x)) & 15u) != 0)
+    return BH_EINVAL;
+  int S = 1, narrow = 0;
+  const int grid = eval_bn_grid(B, C, HW, S, narrow);
+  if (S > 1 && workspace == nullptr) return BH_EINVAL;
+  hipStream_t st = bh::as_stream(stream);
+  hipLaunchKernelGGL(bn_eval_bwd_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, ggx, ggw, ggb, gy, x, weight, inv_std, mean_inv, d_gy,
+                     d_x, d_w, workspace, B, C, HW, S, narrow);
+  if (S > 1 && d_w != nullptr)
+    hipLaunchKernelGGL(bn_eval_combine_kernel<1>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, workspace, inv_std,
+                       mean_inv, d_w, static_cast<float*>(nullptr), C, S);
   return bh::launch_status();
 }
 

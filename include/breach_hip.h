@@ -263,15 +263,19 @@ int bh_bn_bwd_accumulate(const float* x, const float* gin, int32_t hw, const bh_
  * per-channel sums in fp64, fixed order.  No allocation, no synchronisation. */
 int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* inv_std, const float* mean_inv, float* y,
                    int32_t B, int32_t C, int32_t HW, void* stream);
+/* Slabs S a channel is cut into for this geometry (1 when B*HW <= 24 576: the whole order is then ONE launch; otherwise
+ * about one per 16 384 elements, at most 64, and the backward orders take a small second launch that adds the per-slab sums in
+ * slab order).  `workspace` below: 2 * C * S doubles (may be NULL when S == 1). */
+int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW);
 /* gx = gy * s_c (skipped when gx is NULL); gw_c = inv_std_c * sum(gy * x) - mean_inv_c * sum(gy); gb_c = sum(gy). */
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
-                   float* gw, float* gb, int32_t B, int32_t C, int32_t HW, void* stream);
+                   float* gw, float* gb, double* workspace, int32_t B, int32_t C, int32_t HW, void* stream);
 /* Derivative of bh_bn_eval_bwd for incoming (ggx [B,C,HW], ggw [C], ggb [C]; each may be NULL = zero):
  * d_gy = ggx * s_c + ggw_c * (inv_std_c * x - mean_inv_c) + ggb_c;  d_x = ggw_c * inv_std_c * gy;  d_w_c = inv_std_c * sum(ggx * gy).
  * Outputs may be NULL (not computed). */
 int bh_bn_eval_bwd_bwd(const float* ggx, const float* ggw, const float* ggb, const float* gy, const float* x, const float* weight,
-                       const float* inv_std, const float* mean_inv, float* d_gy, float* d_x, float* d_w, int32_t B, int32_t C,
-                       int32_t HW, void* stream);
+                       const float* inv_std, const float* mean_inv, float* d_gy, float* d_x, float* d_w, double* workspace,
+                       int32_t B, int32_t C, int32_t HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Multi-tensor elementwise kernels over per-parameter lists (FedAvg unroll, Pearlmutter offset) and batch kernels

@@ -561,10 +561,10 @@ def test_deepinversion_taps_accumulate_into_the_activation_gradient(kernels_orac
 
 
 @pytest.mark.parametrize("shape,affine", [((1, 64, 112, 112), True), ((2, 12, 7, 7), True), ((3, 5, 9, 11), True), ((1, 512, 7, 7), True),
-                                          ((2, 6, 16, 16), False)])
+                                          ((2, 6, 16, 16), False), ((8, 16, 64, 64), True), ((4, 4, 90, 91), True), ((8, 3, 112, 112), False)])
 def test_eval_batchnorm_function_matches_torch_through_two_orders(shape, affine, hip_lib):
     """The fused eval-mode BatchNorm (`_EvalBNFunction`: one launch forward, one for (gx, gw, gb), one for the derivative of
-    that) against PyTorch's own eval-mode `F.batch_norm` in fp64 on the CPU -- the arithmetic the reference runs -- through
+    that; wave-per-channel, workgroup-per-channel and slab-split (S = 2 and 6, vectorised and scalar) geometries) against PyTorch's own eval-mode `F.batch_norm` in fp64 on the CPU -- the arithmetic the reference runs -- through
     both autograd orders the attack uses: y; d/d(x, w, b) of a scalar of y under create_graph; and the gradient of a scalar
     of THOSE with respect to x (the path from the gradient-matching objective back to the candidate) and w."""
     from breaching_amd.attacker import _EvalAffineBatchNorm2d, use_affine_eval_batchnorm
