@@ -448,14 +448,29 @@ def golden_dlg():
     attacker.objective.forward = inner
     n_loop = len(calls) - 1  # the last call is `_score_trial` on a fresh objective? (no: scoring builds its own module) -- keep all
     picks = sorted({0, 1, 7, 20, 21, 40, len(calls) - 1} & set(range(len(calls))))
-    forced = dict(x=[], p=[], value=[], gx=[], gp=[], call=[])
-    for k in picks:
-        x, p, value = calls[k]
+    forced = dict(x=[], p=[], value=[], gx=[], gp=[], call=[], sens_x=[], sens_p=[], sens_v=[])
+
+    def evaluate(x, p):
         xq, pq = x.clone().requires_grad_(True), p.clone().requires_grad_(True)
         v, _ = attacker.objective(seen["model"], seen["gradient_data"], xq, pq)
         gx, gp = torch.autograd.grad(v, [xq, pq])
-        assert abs(float(v) - value) <= 1e-6 * abs(value)
-        for key, item in zip(("x", "p", "value", "gx", "gp", "call"), (x.numpy(), p.numpy(), value, gx.numpy(), gp.numpy(), k)):
+        return float(v.detach()), gx, gp
+
+    gen = torch.Generator().manual_seed(77)
+    for k in picks:
+        x, p, value = calls[k]
+        v, gx, gp = evaluate(x, p)
+        assert abs(v - value) <= 1e-6 * abs(value)
+        # kink sensitivity of the reference's OWN closure at this point: the iterates L-BFGS visits late in the run sit on
+        # ReLU / max-pool kinks, where moving the candidate by 16 ulp flips units and changes the gradient by a finite amount
+        sens_v = sens_x = sens_p = 0.0
+        for _ in range(4):
+            v2, gx2, gp2 = evaluate(_ulp_perturb(x, 16, gen), p)
+            sens_v = max(sens_v, abs(v2 - v) / abs(v))
+            sens_x = max(sens_x, float((gx2 - gx).abs().max() / gx.abs().max()))
+            sens_p = max(sens_p, float((gp2 - gp).abs().max() / gp.abs().max()))
+        for key, item in zip(("x", "p", "value", "gx", "gp", "call", "sens_x", "sens_p", "sens_v"),
+                             (x.numpy(), p.numpy(), value, gx.numpy(), gp.numpy(), k, sens_x, sens_p, sens_v)):
             forced[key].append(item)
     out = dict(history=np.asarray(stats["Trial_0_Val"], dtype=np.float64), opt_value=np.float64(stats["opt_value"]),
                rec=rec["data"].numpy(), labels=rec["labels"].numpy(), seed=np.int64(5),
@@ -463,7 +478,8 @@ def golden_dlg():
                model_checksum=np.float64(parameter_checksum(case.model)), n_objective_calls=np.int64(len(calls)),
                forced_call=np.asarray(forced["call"], dtype=np.int64), forced_x=np.stack(forced["x"]), forced_p=np.stack(forced["p"]),
                forced_value=np.asarray(forced["value"], dtype=np.float64), forced_gx=np.stack(forced["gx"]),
-               forced_gp=np.stack(forced["gp"]))
+               forced_gp=np.stack(forced["gp"]), forced_sensitivity_x=np.asarray(forced["sens_x"]),
+               forced_sensitivity_p=np.asarray(forced["sens_p"]), forced_sensitivity_value=np.asarray(forced["sens_v"]))
     np.savez_compressed(os.path.join(GOLDEN, "attack_dlg.npz"), **out)
 
 

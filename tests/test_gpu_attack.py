@@ -529,18 +529,26 @@ def test_deep_leakage_closure_at_the_reference_iterates(golden_dir):
     rec_models, _, _ = attacker.prepare_attack(case.server_payload, case.shared_data)
     attacker.objective.initialize(attacker.loss_fn, cfg.impl, case.shared_data[0]["metadata"]["local_hyperparams"])
     assert int(gold["n_objective_calls"]) == 60 and len(gold["forced_call"]) >= 6
-    for k, x, p, want, gx_ref, gp_ref in zip(gold["forced_call"], gold["forced_x"], gold["forced_p"], gold["forced_value"],
-                                             gold["forced_gx"], gold["forced_gp"]):
+    strict = 0
+    for idx, (k, x, p, want, gx_ref, gp_ref) in enumerate(zip(gold["forced_call"], gold["forced_x"], gold["forced_p"],
+                                                            gold["forced_value"], gold["forced_gx"], gold["forced_gp"])):
         xq = torch.as_tensor(x, device="cuda:0").requires_grad_(True)
         pq = torch.as_tensor(p, device="cuda:0").requires_grad_(True)
         value, _ = attacker.objective(rec_models[0], case.shared_data[0]["gradients"], xq, pq)
         gx, gp = torch.autograd.grad(value, [xq, pq])
+        value = float(value.detach())
         err_x = float(np.abs(gx.cpu().numpy() - gx_ref).max() / np.abs(gx_ref).max())
         err_p = float(np.abs(gp.cpu().numpy() - gp_ref).max() / np.abs(gp_ref).max())
-        print(f"  call {int(k):2d}: reference {want:.6e}  hip {float(value):.6e}  rel {abs(float(value) - want) / want:.1e}  "
-              f"grad x {err_x:.1e}  grad labels {err_p:.1e} of peak")
-        assert float(value) == pytest.approx(float(want), rel=LOSS_RTOL)
-        assert err_x <= 1e-4 and err_p <= 1e-4
+        # The iterates L-BFGS visits sit on ReLU / max-pool kinks: the fixture records how much the REFERENCE's own closure
+        # moves when such a point is moved by 16 ulp (a flipped unit changes the gradient by a finite amount -- up to 1.5 % of
+        # its peak late in the run, 1e-6 at the clean points).  Tolerance: 1e-4, or 3x that recorded sensitivity.
+        sx, sp, sv = (float(gold[f"forced_sensitivity_{n}"][idx]) for n in ("x", "p", "value"))
+        print(f"  call {int(k):2d}: reference {want:.6e}  hip {value:.6e}  rel {abs(value - want) / want:.1e} (kink {sv:.1e})  "
+              f"grad x {err_x:.1e} (kink {sx:.1e})  grad labels {err_p:.1e} (kink {sp:.1e}) of peak")
+        assert value == pytest.approx(float(want), rel=max(LOSS_RTOL, 3 * sv))
+        assert err_x <= max(1e-4, 3 * sx) and err_p <= max(1e-4, 3 * sp)
+        strict += int(abs(value - want) <= LOSS_RTOL * want and err_x <= 1e-4 and err_p <= 1e-4)
+    assert strict >= 3  # the kink-free points (calls 1, 7, 40 in the fixture) are held to the strict 1e-4
 
 
 @pytest.mark.parametrize("name,plain", [("pearlmutter-loss", "euclidean"), ("pearlmutter-cosine", "cosine-similarity")])
