@@ -871,7 +871,8 @@ class _EvalBNFunction(torch.autograd.Function):
     under create_graph=True, then optimization_based_attack.py:160)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, inv_std, mean_inv):
+    def forward(ctx, x, weight, bias, inv_std, mean_inv, stats=None):
+        """`stats`: fp64 view of 2 * C * S words that receives sum(x), sum(x^2) per (channel, slab) -- kernel D's input."""
         lib = _lib.load()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
@@ -879,7 +880,8 @@ class _EvalBNFunction(torch.autograd.Function):
         y = torch.empty_like(xk)
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_fwd(_lib.ptr(xk), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(inv_std), _lib.ptr(mean_inv),
-                                          _lib.ptr(y), B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_fwd")
+                                          _lib.ptr(y), _lib.ptr(stats), B, C, hw, _lib.current_stream_handle(x.device)),
+                       "bh_bn_eval_fwd")
         # the INPUT itself is saved (not the detached kernel view): the backward below is differentiable with respect to it
         ctx.save_for_backward(x, weight, inv_std, mean_inv)
         ctx.has_bias = bias is not None
@@ -889,7 +891,7 @@ class _EvalBNFunction(torch.autograd.Function):
     def backward(ctx, gy):
         x, weight, inv_std, mean_inv = ctx.saved_tensors
         gx, gw, gb = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv)
-        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None
+        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None
 
 
 class _EvalBNGradFunction(torch.autograd.Function):
@@ -956,12 +958,22 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
 
     eval_mode = "hip"
 
+    def _runs_on_hip(self, x):
+        return (not self.training and self.running_mean is not None and self.running_var is not None and x.dim() == 4
+                and self.eval_mode == "hip" and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0)
+
+    def accepts_stats_sink(self, x):
+        """True when the coming forward of `x` will go through kernel E and can fill a per-(channel, slab) statistics buffer
+        (the DeepInversion prior's taps ask, priors._BnInputTap)."""
+        return self._runs_on_hip(x)
+
     def forward(self, x):
+        sink = self.__dict__.pop("_bn_stats_sink", None)  # set by a DeepInversion tap for this one call
         if self.training or self.running_mean is None or self.running_var is None or x.dim() != 4:
             return super().forward(x)
         inv_std, mean_inv = self._frozen_statistics()
-        if self.eval_mode == "hip" and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0:
-            return _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv)
+        if self._runs_on_hip(x):
+            return _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv, sink)
         if self.weight is not None:
             scale = self.weight * inv_std
             shift = -(self.weight * mean_inv)

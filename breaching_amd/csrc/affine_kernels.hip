@@ -21,14 +21,16 @@ namespace {
 
 using bh::kBlock;
 
-// Geometry shared by the three kernels: x is [B, C, HW] contiguous; the B planes of a channel form one virtual array of
-// B * HW elements.  Narrow (B * HW <= kNarrow): one wavefront per channel, four channels per workgroup.  Otherwise a channel
-// is cut into S slabs of about kSlabTarget elements, one workgroup each (S = 1 for every ResNet-18 layer at B = 1: the whole
-// order is one launch); with S > 1 the per-slab channel sums go to a workspace and a small second launch finishes them --
-// large activations (ResNet-50 at B = 8: up to 100 k elements per channel) would otherwise be streamed by C workgroups only.
-constexpr int kNarrow = 512;
-constexpr int kSlabTarget = 16384;
-constexpr int kMaxSlabs = 64;
+// Geometry shared by the three kernels (bh::channel_geometry, the rule of kernel D's forward): x is [B, C, HW] contiguous; the
+// B planes of a channel form one virtual array of B * HW elements.  Narrow (fewer than 2048): one wavefront per channel, four
+// channels per workgroup.  Otherwise a channel is cut into S slabs of about 8192 elements, one workgroup each (S = 1 for every
+// ResNet-18 layer at B = 1 but the stem); with S > 1 the per-slab channel sums of the backward orders go to a workspace and a
+// small second launch adds them in slab order -- large activations (ResNet-50 at B = 8: 100 k elements per channel) would
+// otherwise be streamed by C workgroups only.
+//
+// The forward can also hand kernel D its input: with `stats` given it writes sum(x) and sum(x^2) per (channel, slab) in exactly
+// the layout bn_finalize_kernel reads -- the DeepInversion prior's statistics (deepinversion.py:93-96) of a BatchNorm INPUT
+// come out of the pass that reads that input anyway, and bn_sums_kernel's 355.6 MB re-read (ResNet-50, B = 8) disappears.
 
 struct ChannelWalk {
   int c, slab, lane, lanes;
@@ -73,26 +75,57 @@ __device__ __forceinline__ void channel_sum(double (&v)[K], bool narrow, double*
 
 __global__ __launch_bounds__(kBlock) void bn_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                              const float* __restrict__ bias, const float* __restrict__ inv_std,
-                                                             const float* __restrict__ mean_inv, float* __restrict__ y, int B,
-                                                             int C, int HW, int S, int narrow) {
+                                                             const float* __restrict__ mean_inv, float* __restrict__ y,
+                                                             double* __restrict__ stats, int B, int C, int HW, int S,
+                                                             int narrow) {
+  __shared__ double lds[bh::kWavesPerBlock * 2];
   const ChannelWalk w = channel_of(C, S, narrow != 0);
-  if (!w.active) return;
-  const float wc = weight ? weight[w.c] : 1.f;
-  const float s = wc * inv_std[w.c];
-  const float t = (bias ? bias[w.c] : 0.f) - wc * mean_inv[w.c];
-  const bool vec = (HW & 3) == 0;
-  uint32_t unit, v0, v1;
-  slab_range(B, HW, S, w.slab, vec, unit, v0, v1);
-  const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
-  for (uint32_t v = v0 + (uint32_t)w.lane; v < v1; v += (uint32_t)w.lanes) {
-    const uint32_t b = B == 1 ? 0u : v / unit, j = v - b * unit;
-    const size_t at = (size_t)b * cstride + cbase + j;
-    if (vec) {
-      const float4 q = reinterpret_cast<const float4*>(x)[at];
-      reinterpret_cast<float4*>(y)[at] = make_float4(fmaf(q.x, s, t), fmaf(q.y, s, t), fmaf(q.z, s, t), fmaf(q.w, s, t));
-    } else {
-      y[at] = fmaf(x[at], s, t);
+  double sums[2] = {0.0, 0.0};  // sum x, sum x^2 of this (channel, slab): only with `stats`
+  if (w.active) {
+    const float wc = weight ? weight[w.c] : 1.f;
+    const float s = wc * inv_std[w.c];
+    const float t = (bias ? bias[w.c] : 0.f) - wc * mean_inv[w.c];
+    const bool vec = (HW & 3) == 0;
+    uint32_t unit, v0, v1;
+    slab_range(B, HW, S, w.slab, vec, unit, v0, v1);
+    const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
+    float a0 = 0.f, a1 = 0.f;
+    int cnt = 0;
+    for (uint32_t v = v0 + (uint32_t)w.lane; v < v1; v += (uint32_t)w.lanes) {
+      const uint32_t b = B == 1 ? 0u : v / unit, j = v - b * unit;
+      const size_t at = (size_t)b * cstride + cbase + j;
+      if (vec) {
+        const float4 q = reinterpret_cast<const float4*>(x)[at];
+        reinterpret_cast<float4*>(y)[at] = make_float4(fmaf(q.x, s, t), fmaf(q.y, s, t), fmaf(q.z, s, t), fmaf(q.w, s, t));
+        a0 += (q.x + q.y) + (q.z + q.w);
+        a1 = fmaf(q.x, q.x, a1);
+        a1 = fmaf(q.y, q.y, a1);
+        a1 = fmaf(q.z, q.z, a1);
+        a1 = fmaf(q.w, q.w, a1);
+        cnt += 4;
+      } else {
+        const float q = x[at];
+        y[at] = fmaf(q, s, t);
+        a0 += q;
+        a1 = fmaf(q, q, a1);
+        cnt += 1;
+      }
+      if (cnt >= 32) {  // at most 32 values per fp32 accumulator, like bn_sums_kernel
+        sums[0] += (double)a0;
+        sums[1] += (double)a1;
+        a0 = a1 = 0.f;
+        cnt = 0;
+      }
     }
+    sums[0] += (double)a0;
+    sums[1] += (double)a1;
+  }
+  if (stats == nullptr) return;  // uniform: no barrier is skipped by part of a workgroup
+  channel_sum<2>(sums, narrow != 0, lds);
+  if (w.active && w.lane == 0) {
+    double* out = stats + 2 * ((size_t)w.c * S + w.slab);
+    out[0] = sums[0];
+    out[1] = sums[1];
   }
 }
 
@@ -246,13 +279,7 @@ bool eval_bn_args_ok(const void* x, const void* inv_std, const void* mean_inv, i
 }
 
 int eval_bn_grid(int32_t B, int32_t C, int32_t HW, int& S, int& narrow) {
-  const int64_t per_channel = (int64_t)B * HW;
-  narrow = per_channel <= kNarrow ? 1 : 0;
-  S = 1;
-  if (!narrow) {
-    int64_t s = (per_channel + kSlabTarget / 2) / kSlabTarget;
-    S = (int)(s < 1 ? 1 : (s > kMaxSlabs ? kMaxSlabs : s));
-  }
+  bh::channel_geometry((int64_t)B * HW, S, narrow);
   return narrow ? (C + bh::kWavesPerBlock - 1) / bh::kWavesPerBlock : C * S;
 }
 
@@ -268,13 +295,14 @@ int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW) {
 }
 
 int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* inv_std, const float* mean_inv, float* y,
-                   int32_t B, int32_t C, int32_t HW, void* stream) {
+                   double* stats, int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || y == nullptr) return BH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(stats) & 7u) != 0) return BH_EINVAL;
   if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) != 0) return BH_EINVAL;
   int S = 1, narrow = 0;
   const int grid = eval_bn_grid(B, C, HW, S, narrow);
   hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3(grid), dim3(kBlock), 0, bh::as_stream(stream), x, weight, bias, inv_std, mean_inv,
-                     y, B, C, HW, S, narrow);
+                     y, stats, B, C, HW, S, narrow);
   return bh::launch_status();
 }
 

@@ -48,6 +48,20 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* lds) {
   }
 }
 
+// Channel geometry shared by kernel D's forward (bn_sums) and kernel E (eval-mode BatchNorm): the B planes of a channel form one
+// virtual array of B * HW elements; narrow (fewer than 2048 of them): one wavefront per channel, four channels per workgroup;
+// otherwise the channel is cut into S slabs of about 8192 elements, one workgroup each, at most 64.  Both kernels use the SAME
+// rule so that kernel E's forward can write the per-(channel, slab) sums kernel D's finalize reads.
+constexpr int64_t kChannelSlabTarget = 8192;
+constexpr int64_t kChannelNarrowLimit = 2048;
+constexpr int kChannelMaxSlabs = 64;
+
+inline void channel_geometry(int64_t per_channel, int32_t& S, int32_t& narrow) {
+  narrow = per_channel < kChannelNarrowLimit ? 1 : 0;
+  int64_t s = narrow ? 1 : (per_channel + kChannelSlabTarget / 2) / kChannelSlabTarget;
+  S = (int32_t)(s < 1 ? 1 : (s > kChannelMaxSlabs ? kChannelMaxSlabs : s));
+}
+
 __device__ __forceinline__ float sgnf(float e) { return static_cast<float>((e > 0.f) - (e < 0.f)); }
 
 }  // namespace bh

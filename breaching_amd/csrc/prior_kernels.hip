@@ -527,8 +527,6 @@ void find_divisor(uint32_t d, uint32_t& mul, uint32_t& shr) {
 
 int g_bn_grid_cap = BH_BN_DEFAULT_GRID;        // cap of the forward grid (default: none)
 
-constexpr int64_t kBnTargetPerGroup = 8192;  // elements one forward workgroup should see, roughly
-constexpr int64_t kBnNarrowLimit = 2048;     // B * HW below this: one wavefront per channel
 
 struct BnGeometry {
   int32_t S, narrow;
@@ -539,11 +537,8 @@ bool bn_geometry(int32_t B, int32_t C, int32_t HW, BnGeometry& g) {
   if (B <= 0 || C <= 0 || HW <= 0) return false;
   const int64_t per_channel = (int64_t)B * HW, numel = per_channel * C;
   if (numel >= (int64_t)1 << 31) return false;  // 32-bit indices inside a layer
-  g.narrow = per_channel < kBnNarrowLimit ? 1 : 0;
-  int64_t S = g.narrow ? 1 : (per_channel + kBnTargetPerGroup / 2) / kBnTargetPerGroup;
-  if (S < 1) S = 1;
-  if (S > 64) S = 64;
-  g.S = (int32_t)S;
+  bh::channel_geometry(per_channel, g.S, g.narrow);  // the rule kernel E shares (bh_common.h)
+  const int64_t S = g.S;
   g.fwd_items = g.narrow ? (C + bh::kWavesPerBlock - 1) / bh::kWavesPerBlock : (int64_t)C * S;
   const int64_t units = (HW & 3) == 0 ? numel / 4 : numel;
   const int64_t per_item = (HW & 3) == 0 ? BH_BN_TILE / 4 : BH_BN_TILE;

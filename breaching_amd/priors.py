@@ -153,6 +153,8 @@ class BnStatPlan:
         w = (c_float * n)(*[float(v) for v in weights])
         _lib.check(lib.bh_bn_plan_build(n, B, C, self.hw_host, w, layers, fwd, self.n_fwd, bwd, self.n_bwd), "bh_bn_plan_build")
         self.flat_offsets = [layers[i].flat_off for i in range(n)]
+        self.sums_offsets = [layers[i].sums_off for i in range(n)]       # in (sum, sum of squares) pairs
+        self.layer_pairs = [layers[i].C * layers[i].S for i in range(n)]  # pairs of one layer: C x S
         # per layer: first backward item and item count (the table is built layer by layer) -- the per-layer fused
         # backward-accumulate launches address their slice of it
         counts = [0] * n
@@ -294,20 +296,23 @@ class _BnStatTokenFunction(torch.autograd.Function):
     which then does the per-layer read-modify-write."""
 
     @staticmethod
-    def forward(ctx, plan, ticket, record, xs, *tokens):
+    def forward(ctx, plan, ticket, record, xs, fed_sums, *tokens):
+        """`fed_sums`: the per-(channel, slab) sums buffer when every BatchNorm layer's forward (kernel E) filled its part of
+        it during this pass; None = read the activations here (bh_bn_sums)."""
         lib = _lib.load()
         dev = plan.device
         with torch.cuda.device(dev):
             stream = _lib.current_stream_handle(dev)
-            sums = torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=dev)
+            sums = fed_sums if fed_sums is not None else torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=dev)
             layer_values = torch.empty(plan.n_layers, dtype=torch.float64, device=dev)
             coef = torch.empty(2 * plan.n_channels, dtype=torch.float32, device=dev)
             total = torch.empty(1, dtype=torch.float32, device=dev)
             if ticket is None:
                 ticket = torch.zeros(1, dtype=torch.int32, device=dev)
-            ptrs = plan.pointers(xs)
-            _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
-                                      plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
+            if fed_sums is None:
+                ptrs = plan.pointers(xs)
+                _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
+                                          plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
             _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
                                           _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
                                           _lib.ptr(ticket), stream), "bh_bn_finalize")
@@ -319,7 +324,7 @@ class _BnStatTokenFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, gout):
         gout = gout.contiguous().to(torch.float32)
-        return (None, None, None, None, *([gout] * ctx.n_tokens))
+        return (None, None, None, None, None, *([gout] * ctx.n_tokens))
 
 
 def bn_statistic(x, running_mean, running_var, weight=1.0):
@@ -339,8 +344,10 @@ class _BnInputTap:
     statistic right inside its forward hook, deepinversion.py:93-101; here all layers are evaluated together afterwards,
     and the tap is where their gradient re-enters the graph)."""
 
-    def __init__(self, module, record, layer):
+    def __init__(self, module, record, layer, owner=None, model_idx=0):
         self.module, self.record, self.layer = module, record, layer
+        self.owner, self.model_idx = owner, model_idx
+        self.fed = False   # this pass: the module's own forward kernel writes the layer's channel sums (no bn_sums needed)
         self.x = None      # the activation of the latest forward pass (detached view, what kernel D reads)
         self.token = None  # its token (carries the autograd edge back to the tap)
         self.live = None   # the same activation with its autograd history (only the A/B switch below uses it)
@@ -356,6 +363,15 @@ class _BnInputTap:
             x = x.clone()  # 16-byte vector loads need an aligned base
         tapped, token = _BnTap.apply(x, self.record, self.layer)
         self.x, self.token, self.live = tapped.detach(), token, tapped
+        # Producer-side statistics: when the module's forward is kernel E, let it write sum(x), sum(x^2) of this layer straight
+        # into the prior's sums buffer while it reads x anyway (one-shot attribute, consumed by that forward).
+        self.fed = False
+        accepts = getattr(module, "accepts_stats_sink", None)
+        if self.owner is not None and callable(accepts) and accepts(tapped):
+            sink = self.owner._sink_for(self.model_idx, self.layer, tapped)
+            if sink is not None:
+                module._bn_stats_sink = sink
+                self.fed = True
         return (tapped, *inputs[1:])
 
     def close(self):
@@ -373,6 +389,7 @@ class HipDeepInversion(torch.nn.Module):
         self.losses = []
         self._plans = {}
         self.ticket_scope = None  # dict owned by a trial (FusedTrial.tickets): one re-zeroed ticket word per model
+        self._default_scope = {}  # the same outside the fused loop (generic torch.optim loop, stand-alone use)
 
     def initialize(self, models, *args, **kwargs):
         # The reference re-registers hooks on every trial and never removes the old ones (regularizers.py:214-220);
@@ -386,7 +403,8 @@ class HipDeepInversion(torch.nn.Module):
         for idx, model in enumerate(models):
             for module in model.modules():
                 if isinstance(module, torch.nn.BatchNorm2d):
-                    self.losses[idx].append(_BnInputTap(module, self._records[idx], len(self.losses[idx])))
+                    self.losses[idx].append(_BnInputTap(module, self._records[idx], len(self.losses[idx]), self, idx))
+        self._default_scope = {}
 
     def release_graph(self):
         """Drop the activations of the last forward pass (they hold that pass's autograd graph)."""
@@ -395,6 +413,29 @@ class HipDeepInversion(torch.nn.Module):
                 hook.x = hook.token = hook.live = None
         for record in getattr(self, "_records", []):
             record.coef = None
+
+    def _sums_buffer(self, idx, plan):
+        """The per-(channel, slab) sums of model `idx`: one buffer per trial (trials in flight run on different streams and
+        share the model's modules), or one for this prior outside the fused loop."""
+        scope = self.ticket_scope if self.ticket_scope is not None else self._default_scope
+        buf = scope.get(("bn_sums", idx))
+        if buf is None or buf.numel() != 2 * plan.n_pairs or buf.device != plan.device:
+            buf = scope[("bn_sums", idx)] = torch.empty(2 * plan.n_pairs, dtype=torch.float64, device=plan.device)
+        return buf
+
+    def _sink_for(self, idx, layer, x):
+        """Where kernel E's forward of layer `layer` writes that layer's channel sums this pass, or None (no plan yet -- the
+        shapes are only known after the first pass --, another shape than planned, or BREACH_HIP_BN_PRODUCER_STATS=0)."""
+        import os
+
+        plan = self._plans.get(idx)
+        if plan is None or layer >= plan.n_layers or tuple(x.shape) != plan.shapes[layer] or not accumulate_in_kernel():
+            return None
+        if os.environ.get("BREACH_HIP_BN_PRODUCER_STATS", "1") == "0":
+            return None
+        buf = self._sums_buffer(idx, plan)
+        start = 2 * plan.sums_offsets[layer]
+        return buf[start : start + 2 * plan.layer_pairs[layer]]
 
     def _plan(self, idx, hooks, xs):
         shapes = [x.shape for x in xs]
@@ -425,7 +466,10 @@ class HipDeepInversion(torch.nn.Module):
                     ticket = self.ticket_scope[("bn", idx)] = torch.zeros(1, dtype=torch.int32, device=plan.device)
             if accumulate_in_kernel():
                 tokens = [hook.token for hook in hooks]
-                total = total + _BnStatTokenFunction.apply(plan, ticket, self._records[idx], xs, *tokens)
+                # every layer's forward kernel already wrote its sums this pass (same plan, same trial buffer)?
+                fed = all(hook.fed for hook in hooks) and self._plans.get(idx) is plan
+                fed_sums = self._sums_buffer(idx, plan) if fed else None
+                total = total + _BnStatTokenFunction.apply(plan, ticket, self._records[idx], xs, fed_sums, *tokens)
             else:  # round-2 form, kept for A/B measurements: one backward launch for all layers, autograd adds each layer in
                 total = total + _BnStatFunction.apply(plan, ticket, *[hook.live for hook in hooks])
         return total

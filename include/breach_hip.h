@@ -261,11 +261,14 @@ int bh_bn_bwd_accumulate(const float* x, const float* gin, int32_t hw, const bh_
  * attack differentiates twice per iteration (objectives.py:40-46 with create_graph=True, optimization_based_attack.py:160).
  * x / y / gradients: [B, C, HW] contiguous fp32 (16-byte aligned when HW % 4 == 0); weight / bias may be NULL (affine=False);
  * per-channel sums in fp64, fixed order.  No allocation, no synchronisation. */
+/* `stats` (may be NULL): 2 * C * S doubles receiving sum(x) and sum(x^2) per (channel, slab), S = bh_bn_eval_slabs -- the layout
+ * bh_bn_finalize reads for a layer (point it at sums_dev + 2 * sums_off of that layer): the DeepInversion prior's statistics of
+ * a BatchNorm input then come out of the pass that reads the input anyway, and bh_bn_sums is not needed. */
 int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* inv_std, const float* mean_inv, float* y,
-                   int32_t B, int32_t C, int32_t HW, void* stream);
-/* Slabs S a channel is cut into for this geometry (1 when B*HW <= 24 576: the whole order is then ONE launch; otherwise
- * about one per 16 384 elements, at most 64, and the backward orders take a small second launch that adds the per-slab sums in
- * slab order).  `workspace` below: 2 * C * S doubles (may be NULL when S == 1). */
+                   double* stats, int32_t B, int32_t C, int32_t HW, void* stream);
+/* Slabs S a channel is cut into for this geometry -- the rule of bh_bn_plan_build (1 below 12 288 elements per channel: the
+ * whole order is then ONE launch; otherwise about one per 8 192 elements, at most 64, and the backward orders take a small
+ * second launch that adds the per-slab sums in slab order).  `workspace` below: 2 * C * S doubles (may be NULL when S == 1). */
 int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW);
 /* gx = gy * s_c (skipped when gx is NULL); gw_c = inv_std_c * sum(gy * x) - mean_inv_c * sum(gy); gb_c = sum(gy). */
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,

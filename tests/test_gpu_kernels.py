@@ -610,3 +610,54 @@ def test_eval_batchnorm_function_matches_torch_through_two_orders(shape, affine,
     close(got[2][0], ref[2][0], "second order wrt x")
     if affine:
         close(got[2][1], ref[2][1], "second order wrt weight")
+
+
+def test_deepinversion_statistics_come_from_the_batchnorm_forward_kernel(kernels_oracle, hip_lib, monkeypatch):
+    """With the eval-mode BatchNorm layers on kernel E, the DeepInversion prior needs no pass of its own over the activations:
+    from the second evaluation on (the first one learns the shapes and builds the plan) every layer's forward kernel writes
+    sum(x), sum(x^2) per (channel, slab) into the prior's buffer and only bh_bn_finalize runs.  Same value and gradient as the
+    bh_bn_sums path (fp64 sums either way) and as the C oracle; wide / slab-split / narrow / scalar layers."""
+    from breaching_amd.attacker import use_affine_eval_batchnorm
+    from breaching_amd.priors import HipDeepInversion
+    from oracle import kernels_ref
+
+    torch.manual_seed(5)
+    dev = _dev()
+    model = torch.nn.Sequential(
+        torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.Tanh(),
+        torch.nn.Conv2d(8, 12, 3, stride=2, padding=1), torch.nn.BatchNorm2d(12), torch.nn.Tanh(),
+        torch.nn.Conv2d(12, 6, 3, stride=2, padding=0), torch.nn.BatchNorm2d(6)).to(dev).eval()
+    bns = [m for m in model if isinstance(m, torch.nn.BatchNorm2d)]
+    for bn in bns:
+        bn.running_mean.normal_(0, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    use_affine_eval_batchnorm(model, "hip")
+    x = torch.randn(4, 3, 112, 112, device=dev, requires_grad=True)  # BN inputs [4,8,112,112] (S = 6), [4,12,56,56] (S = 2), [4,6,27,27] (S = 1, scalar)
+    prior = HipDeepInversion(dict(device=dev, dtype=torch.float), scale=0.25, first_bn_multiplier=10)
+    prior.initialize([model])
+
+    def evaluate():
+        xq = x.detach().clone().requires_grad_(True)
+        out = model(xq)
+        value = prior(xq)
+        (g,) = torch.autograd.grad((out ** 2).mean() + 0.7 * value, xq)
+        return float(value), g, [h.fed for h in prior.losses[0]]
+
+    v1, g1, fed1 = evaluate()
+    v2, g2, fed2 = evaluate()
+    assert fed1 == [False] * 3 and fed2 == [True] * 3  # plan known from the second pass on
+    monkeypatch.setenv("BREACH_HIP_BN_PRODUCER_STATS", "0")
+    v3, g3, fed3 = evaluate()
+    assert fed3 == [False] * 3
+    assert abs(v2 - v1) <= 2e-6 * abs(v1) and abs(v3 - v1) <= 2e-6 * abs(v1)
+    _assert_grads([g2.cpu().numpy()], [g1.cpu().numpy().astype(np.float64)], rtol=2e-5)
+    _assert_grads([g3.cpu().numpy()], [g1.cpu().numpy().astype(np.float64)], rtol=2e-5)
+    # against the C oracle on the activations themselves
+    acts = []
+    hooks = [bn.register_forward_hook(lambda m, i, o: acts.append(i[0].detach())) for bn in bns]
+    model(x.detach())
+    for h in hooks:
+        h.remove()
+    want = sum(0.25 * (10 if i == 0 else 1) * kernels_ref.bnstat(a.cpu().numpy(), bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy())[0]
+               for i, (a, bn) in enumerate(zip(acts, bns)))
+    assert abs(v2 - want) <= 5e-6 * abs(want)
