@@ -81,6 +81,14 @@ class TrialShard:
         else:
             local_key = score_key(float("inf"), 0xFFFFFFFF)
         collective = self.world > 1 or self.always_collective
+        if collective and torch.device(device).type == "cuda":
+            # object collectives (the stats gather, the shapes fallback) place their buffers on the CURRENT device: make that
+            # the rank's own GPU for the whole selection, whatever the caller's current device is
+            with torch.cuda.device(device):
+                return self._select(local_key, local_solutions, stats, device, gather_stats, collective)
+        return self._select(local_key, local_solutions, stats, device, gather_stats, collective)
+
+    def _select(self, local_key, local_solutions, stats, device, gather_stats, collective):
         if not collective:
             best_key = local_key
         else:
