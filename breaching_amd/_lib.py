@@ -122,6 +122,9 @@ _PROTOTYPES = {
     "bh_bn_eval_slabs": (c_int32, [c_int32, c_int32, c_int32]),
     "bh_bn_eval_bwd": (c_int, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_void_p]),
     "bh_bn_eval_bwd_bwd": (c_int, [c_void_p] * 12 + [c_int32, c_int32, c_int32, c_void_p]),
+    "bh_ln_fwd": (c_int, [c_void_p] * 6 + [c_int32, c_int32, ctypes.c_float, c_void_p]),
+    "bh_ln_bwd": (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_void_p]),
+    "bh_ln_bwd_bwd": (c_int, [c_void_p] * 12 + [c_int32, c_int32, c_void_p]),
     "bh_bn_set_grid_cap": (c_int, [c_int32]),
     "bh_bn_set_finalize_block": (c_int, [c_int32]),
     "bh_bn_set_load_depth": (c_int, [c_int32]),

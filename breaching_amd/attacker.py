@@ -335,6 +335,8 @@ class HipOptimizationAttacker:
             bn_mode = fast_eval_bn_mode(self.cfg)
             if bn_mode is not None:
                 use_affine_eval_batchnorm(new_model, bn_mode)
+            if fast_layer_norm_enabled(self.cfg):
+                use_hip_layernorm(new_model)
             models.append(new_model)
         return models
 
@@ -1026,6 +1028,112 @@ def fast_eval_bn_mode(cfg):
 
 def fast_eval_bn_enabled(cfg):
     return fast_eval_bn_mode(cfg) is not None
+
+
+class _LayerNormFunction(torch.autograd.Function):
+    """LayerNorm over the last dimension as ONE launch (bh_ln_fwd); its backward is `_LayerNormGradFunction`, itself
+    differentiable -- the text attacks need the derivative of the first-order pass (objectives.py:40-46 under
+    create_graph=True, then optimization_with_label_attack.py:168-174)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        lib = _lib.load()
+        D = x.shape[-1]
+        xk = x.detach().contiguous()
+        R = xk.numel() // D
+        y = torch.empty_like(xk)
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bh_ln_fwd(_lib.ptr(xk), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(y), _lib.ptr(mean), _lib.ptr(rstd), R, D,
+                                     float(eps), _lib.current_stream_handle(x.device)), "bh_ln_fwd")
+        ctx.save_for_backward(x, weight, mean, rstd)  # the input itself: the backward below is differentiable in it
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        gx, gw, gb = _LayerNormGradFunction.apply(gy, x, weight, mean, rstd)
+        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None
+
+
+class _LayerNormGradFunction(torch.autograd.Function):
+    """(gy, x, weight) -> (gx, gweight, gbias) in two launches (bh_ln_bwd: rows, then columns); backward = the derivative of
+    that map (bh_ln_bwd_bwd: rows, then columns for d_weight).  `mean` / `rstd` are cached functions of x: the derivative
+    with respect to x accounts for them.  PyTorch's decomposition of the same orders is ~83 launches per layer."""
+
+    @staticmethod
+    def forward(ctx, gy, x, weight, mean, rstd):
+        lib = _lib.load()
+        D = x.shape[-1]
+        xk = x.detach().contiguous()
+        gyk = gy.detach().to(torch.float32).contiguous()
+        R = xk.numel() // D
+        gx = torch.empty_like(xk)
+        gw = torch.empty(D, dtype=torch.float32, device=x.device)
+        gb = torch.empty(D, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bh_ln_bwd(_lib.ptr(gyk), _lib.ptr(xk), _lib.ptr(weight), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(gx),
+                                     _lib.ptr(gw), _lib.ptr(gb), R, D, _lib.current_stream_handle(x.device)), "bh_ln_bwd")
+        ctx.save_for_backward(gyk, xk, weight, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return gx, gw, gb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, u, s, t):
+        lib = _lib.load()
+        gy, x, weight, mean, rstd = ctx.saved_tensors
+        if u is None and s is None and t is None:
+            return None, None, None, None, None
+        D = x.shape[-1]
+        R = x.numel() // D
+        u = None if u is None else u.to(torch.float32).contiguous()
+        s = None if s is None else s.to(torch.float32).contiguous()
+        t = None if t is None else t.to(torch.float32).contiguous()
+        d_gy = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        d_x = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        want_dw = weight is not None and ctx.needs_input_grad[2] and u is not None
+        d_w = torch.empty(D, dtype=torch.float32, device=x.device) if want_dw else None
+        rows = torch.empty(2 * R, dtype=torch.float32, device=x.device) if want_dw else None
+        if d_gy is None and d_x is None and d_w is None:
+            return None, None, None, None, None
+        with torch.cuda.device(x.device):
+            _lib.check(lib.bh_ln_bwd_bwd(_lib.ptr(u), _lib.ptr(s), _lib.ptr(t), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight),
+                                         _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(d_gy), _lib.ptr(d_x), _lib.ptr(d_w), _lib.ptr(rows), R, D,
+                                         _lib.current_stream_handle(x.device)), "bh_ln_bwd_bwd")
+        return d_gy, d_x, d_w, None, None
+
+
+class _HipLayerNorm(torch.nn.LayerNorm):
+    """torch.nn.LayerNorm (same parameters, hooks, `isinstance`; instances converted by swapping ``__class__``) whose forward is
+    kernel F when it normalises the last dimension of an fp32 ROCm tensor; anything else takes the stock path."""
+
+    def forward(self, x):
+        if (len(self.normalized_shape) == 1 and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0
+                and x.shape[-1] == self.normalized_shape[0]):
+            return _LayerNormFunction.apply(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
+def use_hip_layernorm(model):
+    """Convert every plain LayerNorm of `model` in place (idempotent).  On by default; cfg.impl.fast_layer_norm=False or
+    BREACH_HIP_FAST_LN=0 keeps the stock modules."""
+    for module in model.modules():
+        if type(module) is torch.nn.LayerNorm:
+            module.__class__ = _HipLayerNorm
+    return model
+
+
+def fast_layer_norm_enabled(cfg):
+    import os
+
+    env = os.environ.get("BREACH_HIP_FAST_LN")
+    if env is not None:
+        return env.strip().lower() not in ("0", "false", "off", "no")
+    flag = _cfg_get(cfg.impl, "fast_layer_norm", True)
+    return True if flag is None else bool(flag)
 
 
 def trials_in_flight(cfg):

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libbreach_hip.so")
 STAMP_PATH = os.path.join(LIB_DIR, "libbreach_hip.stamp")
 
-SOURCES = ["gm_kernels.hip", "prior_kernels.hip", "step_kernels.hip", "mt_kernels.hip", "affine_kernels.hip"]
+SOURCES = ["gm_kernels.hip", "prior_kernels.hip", "step_kernels.hip", "mt_kernels.hip", "affine_kernels.hip", "layernorm_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "bh_common.h"), os.path.join(INCLUDE, "breach_hip.h")]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]

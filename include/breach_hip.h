@@ -281,6 +281,26 @@ int bh_bn_eval_bwd_bwd(const float* ggx, const float* ggw, const float* ggb, con
                        int32_t B, int32_t C, int32_t HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension (elementwise affine) of the attacker's private model copy, one or two launches per
+ * autograd order.  reference: the text attacks (config/attack/tag.yaml, optimization_with_label_attack.py:168-174 ->
+ * objectives.py:40-46) differentiate every LayerNorm of the rebuilt victim model (base_attack.py:176-212) twice per
+ * iteration.  x / y / gradients: [R, D] contiguous fp32 (R = all leading dimensions); gamma / beta [D] may be NULL.
+ * Row sums in fp64, column sums in a fixed order; no allocation, no synchronisation. */
+int bh_ln_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, int32_t R, int32_t D,
+              float eps, void* stream);
+/* gx = rstd (g - M(g) - x_hat M(g x_hat)), g = gy gamma (skipped when gx is NULL); ggamma = sum_r gy x_hat; gbeta = sum_r gy
+ * (one more launch; skipped when both are NULL).  mean / rstd: the [R] arrays bh_ln_fwd wrote. */
+int bh_ln_bwd(const float* gy, const float* x, const float* gamma, const float* mean, const float* rstd, float* gx, float* ggamma,
+              float* gbeta, int32_t R, int32_t D, void* stream);
+/* Derivative of bh_ln_bwd for incoming u = d/d gx [R, D], s = d/d ggamma [D], t = d/d gbeta [D] (each may be NULL = zero):
+ * d_gy = gamma rstd P u + s x_hat + t;  d_x = -rstd^2 (M(u w) x_hat + b P u + M(u x_hat) w) + rstd P (s gy);
+ * d_gamma = sum_r gy rstd P u  (P v = v - M(v) - x_hat M(v x_hat), w = P g, b = M(g x_hat)).  Outputs may be NULL;
+ * `row_scalars`: 2 * R floats of workspace, required for d_gamma. */
+int bh_ln_bwd_bwd(const float* u, const float* s, const float* t, const float* gy, const float* x, const float* gamma,
+                  const float* mean, const float* rstd, float* d_gy, float* d_x, float* d_gamma, float* row_scalars, int32_t R,
+                  int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Multi-tensor elementwise kernels over per-parameter lists (FedAvg unroll, Pearlmutter offset) and batch kernels
  * ---------------------------------------------------------------------------------------------------------------- */
 

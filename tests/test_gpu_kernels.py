@@ -661,3 +661,51 @@ def test_deepinversion_statistics_come_from_the_batchnorm_forward_kernel(kernels
     want = sum(0.25 * (10 if i == 0 else 1) * kernels_ref.bnstat(a.cpu().numpy(), bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy())[0]
                for i, (a, bn) in enumerate(zip(acts, bns)))
     assert abs(v2 - want) <= 5e-6 * abs(want)
+
+
+@pytest.mark.parametrize("shape,affine", [((1, 32, 768), True), ((2, 8, 64), True), ((7, 130), True), ((3, 5, 37), False), ((300, 96), True)])
+def test_layernorm_function_matches_torch_through_two_orders(shape, affine, hip_lib):
+    """Kernel F (`_LayerNormFunction`: forward, (gx, gweight, gbias), and the derivative of that) against PyTorch's own
+    `F.layer_norm` in fp64 on the CPU -- the arithmetic the reference runs -- through both autograd orders the text attacks
+    use; BERT-base's 32 x 768, ragged widths, many rows, no affine parameters."""
+    from breaching_amd.attacker import _HipLayerNorm, use_hip_layernorm
+
+    torch.manual_seed(sum(shape))
+    D = shape[-1]
+    ln = torch.nn.LayerNorm(D, elementwise_affine=affine, eps=1e-12)
+    if affine:
+        with torch.no_grad():
+            ln.weight.normal_(1.0, 0.3)
+            ln.bias.normal_(0, 0.2)
+    x_cpu = torch.randn(shape, dtype=torch.float64) * 1.5 + 0.3
+    mix1, mix2 = torch.randn(shape, dtype=torch.float64), torch.randn(shape, dtype=torch.float64)
+    mw, mb = torch.randn(D, dtype=torch.float64), torch.randn(D, dtype=torch.float64)
+
+    def run(module, x, cast):
+        x = x.clone().requires_grad_(True)
+        params = [p for p in module.parameters()]
+        y = module(x)
+        first = torch.autograd.grad((y * y * cast(mix1)).sum(), [x, *params], create_graph=True)
+        scalar = (first[0] * cast(mix2)).sum()
+        if params:
+            scalar = scalar + (first[1] * cast(mw)).sum() + (first[2] * cast(mb)).sum()
+        second = torch.autograd.grad(scalar, [x, *params[:1]], allow_unused=True)
+        return y.detach(), [f.detach() for f in first], [None if g is None else g.detach() for g in second]
+
+    import copy
+    ref = run(copy.deepcopy(ln).double(), x_cpu, lambda t: t)
+    hip_ln = use_hip_layernorm(copy.deepcopy(ln).to(_dev()))
+    assert type(hip_ln) is _HipLayerNorm
+    got = run(hip_ln, x_cpu.to(_dev(), torch.float32), lambda t: t.to(_dev(), torch.float32))
+
+    def close(a, b, what):
+        a, b = a.cpu().double().numpy(), b.numpy()
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err <= 3e-5, (what, err)
+
+    close(got[0], ref[0], "y")
+    for k, name in enumerate(["gx", "gweight", "gbias"][: len(ref[1])]):
+        close(got[1][k], ref[1][k], name)
+    close(got[2][0], ref[2][0], "second order wrt x")
+    if affine:
+        close(got[2][1], ref[2][1], "second order wrt weight")
