@@ -423,3 +423,50 @@ def test_generic_loop_optimizers_and_schedule_match_reference_on_cpu():
     bad.cfg = get_attack_config("invertinggradients", ["optim.optimizer=adagrad"])
     with pytest.raises(ValueError):
         bad._init_optimizer([torch.zeros(1, requires_grad=True)])
+
+
+def test_implementation_switches(monkeypatch):
+    """cfg.impl / environment switches of the host side: graph capture policy, restarts in flight (clamped to 4), how the
+    eval-mode BatchNorm and LayerNorm layers of the model copy run."""
+    from breaching_amd import attacker, get_attack_config
+
+    for name in ("BREACH_HIP_GRAPH", "BREACH_HIP_TRIALS_IN_FLIGHT", "BREACH_HIP_FAST_BN", "BREACH_HIP_FAST_LN"):
+        monkeypatch.delenv(name, raising=False)
+    cfg = get_attack_config("invertinggradients")
+    assert attacker.graph_replay_policy(cfg) == "on" and attacker.graph_replay_enabled(cfg)
+    assert attacker.trials_in_flight(cfg) == attacker.DEFAULT_TRIALS_IN_FLIGHT == 4
+    assert attacker.fast_eval_bn_mode(cfg) == "hip" and attacker.fast_layer_norm_enabled(cfg)
+    cfg = get_attack_config("invertinggradients", ["impl.hip_graph=auto", "impl.trials_in_flight=9", "impl.fast_eval_bn=addcmul",
+                                                   "impl.fast_layer_norm=False"])
+    assert attacker.graph_replay_policy(cfg) == "auto" and attacker.graph_replay_enabled(cfg)
+    assert attacker.trials_in_flight(cfg) == attacker.MAX_TRIALS_IN_FLIGHT  # more than four concurrent replays run slower
+    assert attacker.fast_eval_bn_mode(cfg) == "addcmul" and not attacker.fast_layer_norm_enabled(cfg)
+    cfg = get_attack_config("invertinggradients", ["impl.hip_graph=False", "impl.fast_eval_bn=False", "impl.trials_in_flight=2"])
+    assert attacker.graph_replay_policy(cfg) == "off" and not attacker.graph_replay_enabled(cfg)
+    assert attacker.fast_eval_bn_mode(cfg) is None and not attacker.fast_eval_bn_enabled(cfg) and attacker.trials_in_flight(cfg) == 2
+    monkeypatch.setenv("BREACH_HIP_GRAPH", "auto")
+    monkeypatch.setenv("BREACH_HIP_FAST_BN", "hip")
+    monkeypatch.setenv("BREACH_HIP_FAST_LN", "1")
+    monkeypatch.setenv("BREACH_HIP_TRIALS_IN_FLIGHT", "1")
+    assert attacker.graph_replay_policy(cfg) == "auto" and attacker.fast_eval_bn_mode(cfg) == "hip"
+    assert attacker.fast_layer_norm_enabled(cfg) and attacker.trials_in_flight(cfg) == 1
+
+
+def test_model_copy_modules_are_swapped_in_place():
+    """The eval-BatchNorm / LayerNorm replacements are class swaps: same parameters, buffers, state_dict keys and isinstance."""
+    from breaching_amd.attacker import _EvalAffineBatchNorm2d, _HipLayerNorm, use_affine_eval_batchnorm, use_hip_layernorm
+
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Flatten(), torch.nn.LayerNorm(4 * 6 * 6))
+    keys = list(model.state_dict())
+    params = [id(p) for p in model.parameters()]
+    use_affine_eval_batchnorm(model, "addcmul")
+    use_hip_layernorm(model)
+    assert type(model[1]) is _EvalAffineBatchNorm2d and model[1].eval_mode == "addcmul" and isinstance(model[1], torch.nn.BatchNorm2d)
+    assert type(model[3]) is _HipLayerNorm and isinstance(model[3], torch.nn.LayerNorm)
+    assert list(model.state_dict()) == keys and [id(p) for p in model.parameters()] == params
+    # on CPU both fall through to torch's own arithmetic (the HIP functions need a ROCm tensor): same numbers as the stock modules
+    reference = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Flatten(), torch.nn.LayerNorm(4 * 6 * 6))
+    reference.load_state_dict(model.state_dict())
+    x = torch.randn(2, 3, 8, 8)
+    torch.testing.assert_close(model.eval()(x), reference.eval()(x), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(model.train()(x), reference.train()(x), rtol=1e-5, atol=1e-6)
