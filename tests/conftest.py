@@ -12,6 +12,18 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm GPU (run with `-m gpu` on the MI355X box)")
+    config.addinivalue_line("markers", "trial_pool: the test chooses the trial worker devices itself (cfg.impl.trial_devices)")
+
+
+@pytest.fixture(autouse=True)
+def _restarts_stay_on_one_gpu(request, monkeypatch):
+    """On a multi-GPU box `reconstruct` with several restarts starts one worker process per visible GPU by default.  The
+    parity tests compare single-device trajectories: pin them (and the scripts they spawn) to the attacker's own GPU, whatever
+    the box looks like.  Tests marked `trial_pool` pick their devices themselves."""
+    if request.node.get_closest_marker("trial_pool") is None:
+        monkeypatch.setenv("BREACH_HIP_TRIAL_DEVICES", "0")
+    else:
+        monkeypatch.delenv("BREACH_HIP_TRIAL_DEVICES", raising=False)
 
 
 # Collection order (VERDICT round 2, weak #2): the cheap, deterministic, oracle-anchored tests run FIRST, the end-to-end

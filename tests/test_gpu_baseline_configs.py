@@ -213,6 +213,7 @@ def test_tag_joint_attack_on_bert_base_sequence_32(golden_dir):
 # ---------------------------------------------------------------------------------------------------------------------
 # configs[3]: restarts sharded over worker processes from the single-process entry point
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.trial_pool
 def test_reconstruct_shards_trials_over_worker_processes_and_matches_one_rank():
     """`reconstruct` with num_trials=4 and two ranks (the caller + one spawned worker, both on cuda:0, gloo selection):
     every trial's loss history, the winner, opt_value and the returned candidate equal the single-rank run.  Non-chaotic
@@ -258,6 +259,7 @@ def test_reconstruct_shards_trials_over_worker_processes_and_matches_one_rank():
     assert_same_attack((rec2, stats2), (rec1, stats1))
 
 
+@pytest.mark.trial_pool
 def test_worker_pool_runs_a_fedavg_multi_step_attack():
     """The pool path with a FedAvg (multi-step) user update: `metadata.local_hyperparams["labels"]` travels to the worker as host
     tensors and has to be moved to that rank's device there (round-2 advisor finding: the reference only casts gradients and
@@ -296,3 +298,38 @@ def test_worker_pool_runs_a_fedavg_multi_step_attack():
         assert a[0] == pytest.approx(b[0], rel=1e-5)
         np.testing.assert_allclose(a, b, rtol=1e-2)
     assert stats2["opt_value"] == pytest.approx(stats1["opt_value"], rel=5e-2)
+
+
+@pytest.mark.trial_pool
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least two GPUs (the RCCL path between ranks)")
+def test_restarts_over_all_visible_gpus_through_rccl():
+    """Only on a multi-GPU box (collected last on purpose): `reconstruct` with four restarts and the DEFAULT device choice --
+    one worker process per visible GPU, "nccl" = RCCL over xGMI for the selection -- against the same attack on one GPU.
+    Smooth configuration; run-vs-run limits of conftest.RUN_VS_RUN (different GPUs may run different convolution algorithms)."""
+    import torch.distributed as dist
+    from conftest import assert_same_attack
+
+    import breaching_amd
+    from breaching_amd.cases import build_case
+
+    over = ["objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft", "optim.max_iterations=10",
+            "restarts.num_trials=4", "restarts.scoring=euclidean", "optim.callback=5"]
+    case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float)
+    results = {}
+    for devices in ("[0]", "all"):
+        cfg = breaching_amd.get_attack_config("invertinggradients", over + [f"impl.trial_devices={devices}", "impl.trial_pool=required"])
+        attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
+        try:
+            torch.manual_seed(3)
+            shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+            rec, stats = attacker.reconstruct(case.server_payload, shared, {})
+            if devices == "all":
+                pool = stats["execution"]["pool"]
+                assert pool is not None and pool["backend"] == "nccl" and pool["world"] == min(4, torch.cuda.device_count())
+                assert len(set(pool["devices"])) == pool["world"]
+            results[devices] = (rec["data"].cpu(), dict(stats))
+        finally:
+            attacker.close()
+        assert not dist.is_initialized()
+    assert_same_attack(results["all"], results["[0]"])
