@@ -257,3 +257,44 @@ def test_forward_rows_and_mt_group_bounds_host_arithmetic(hip_lib):
     assert list(bounds) == [0, 128, 256, 300]
     assert all(chunks[i].tensor == i for i in range(n))
     assert hip_lib.bh_mt_group_bounds(300, chunks, n, None) == -1
+
+
+def test_kernel_e_and_d_share_the_channel_geometry(hip_lib):
+    """Kernel E's forward writes the per-(channel, slab) sums kernel D's finalize reads: both must cut a channel into the same
+    number of slabs for every geometry (host arithmetic only: bh_bn_eval_slabs vs the S of bh_bn_plan_build)."""
+    from ctypes import byref, c_float, c_int32, c_int64
+
+    from breaching_amd import _lib
+
+    shapes = [(1, 64, 112 * 112), (8, 64, 112 * 112), (8, 256, 56 * 56), (2, 64, 112 * 112), (8, 512, 28 * 28), (8, 1024, 14 * 14),
+              (8, 2048, 7 * 7), (1, 512, 7 * 7), (1, 3, 2047), (1, 3, 2048), (1, 3, 12287), (1, 3, 12288), (4, 6, 27 * 27), (64, 2, 8192)]
+    n = len(shapes)
+    B, C, HW = [(c_int32 * n)(*[s[k] for s in shapes]) for k in range(3)]
+    sizes = [c_int64() for _ in range(5)]
+    assert hip_lib.bh_bn_plan_size(n, B, C, HW, *[byref(v) for v in sizes]) == 0
+    n_fwd, n_bwd = sizes[0].value, sizes[1].value
+    layers, fwd, bwd = (_lib.BnLayer * n)(), (_lib.BnItem * n_fwd)(), (_lib.BnItem * n_bwd)()
+    assert hip_lib.bh_bn_plan_build(n, B, C, HW, (c_float * n)(*([1.0] * n)), layers, fwd, n_fwd, bwd, n_bwd) == 0
+    for l, (b, c, hw) in enumerate(shapes):
+        assert hip_lib.bh_bn_eval_slabs(b, c, hw) == layers[l].S, (b, c, hw)
+        assert (layers[l].S == 1) == (b * hw < 12288)
+    assert hip_lib.bh_bn_eval_slabs(0, 1, 1) == -1
+
+
+def test_model_kernels_reject_bad_arguments_before_launching(hip_lib):
+    """Kernels E / F / the per-layer accumulate validate their arguments on the host and return BH_EINVAL without touching the
+    GPU (callable here without one): null required pointers, non-positive sizes."""
+    ok = 16  # a non-null, 16-byte aligned fake address: validation never dereferences
+    assert hip_lib.bh_bn_eval_fwd(None, None, None, ok, ok, ok, None, 1, 4, 16, None) == -1          # x missing
+    assert hip_lib.bh_bn_eval_fwd(ok, None, None, ok, ok, None, None, 1, 4, 16, None) == -1          # y missing
+    assert hip_lib.bh_bn_eval_fwd(ok, None, None, ok, ok, ok, None, 0, 4, 16, None) == -1            # B = 0
+    assert hip_lib.bh_bn_eval_fwd(ok + 4, None, None, ok, ok, ok, None, 1, 4, 16, None) == -1        # misaligned for 16-byte access
+    assert hip_lib.bh_bn_eval_bwd(None, ok, None, ok, ok, ok, ok, ok, None, 1, 4, 16, None) == -1    # gy missing
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, 8, 4, 112 * 112, None) == -1  # S > 1 needs a workspace
+    assert hip_lib.bh_bn_eval_bwd_bwd(None, None, None, None, ok, None, ok, ok, ok, ok, None, None, 1, 4, 16, None) == -1
+    assert hip_lib.bh_ln_fwd(None, None, None, ok, ok, ok, 4, 8, 1e-5, None) == -1
+    assert hip_lib.bh_ln_fwd(ok, None, None, ok, None, ok, 4, 8, 1e-5, None) == -1                   # mean missing
+    assert hip_lib.bh_ln_bwd(None, ok, None, ok, ok, ok, ok, ok, 4, 8, None) == -1
+    assert hip_lib.bh_ln_bwd_bwd(ok, None, None, ok, ok, None, ok, ok, ok, ok, ok, None, 4, 8, None) == -1  # d_gamma needs row scalars
+    assert hip_lib.bh_bn_bwd_accumulate(None, None, 16, ok, ok, 1, ok, None, ok, None) == -1
+    assert hip_lib.bh_bn_bwd_accumulate(ok, None, 16, ok, ok, 0, ok, None, ok, None) == -1
