@@ -1,3 +1,5 @@
+# (historical: run at commit 32ae57f, where kernel D's fused forward -- BREACH_HIP_BN_FUSED -- still existed; kept as the producer of
+#  profiles/r3_kernel_bench_with_fused_bn_forward.json)
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
