@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz by running the UNMODIFIED reference in the build container.
 
     python -m oracle.make_golden [--only configs|kernels|schedules|convnet|resnet18|seethrough|tag|variants|fedavg|labels|dlg|multiquery|pearlmutter]
-    python -m oracle.make_golden --only resnet18_long|seethrough_b8|tag_bert_base      (slow: run by name only)
+    python -m oracle.make_golden --only resnet18_long|seethrough_b8|tag_bert_base|resnet18_24k   (slow: run by name only)
 
 Needs /root/reference (through oracle/ref_shim.py); the outputs are committed so that the GPU box -- which has no
 reference checkout -- can pin oracle/restate.py, oracle/kernels_oracle.c and the HIP path against real reference
@@ -595,6 +595,161 @@ def golden_resnet18_long(parallel=4):
     np.savez_compressed(os.path.join(GOLDEN, "attack_resnet18_long.npz"), **main)
 
 
+# ---- BASELINE configs[1] at its STATED horizon: 24 000 iterations --------------------------------------------------
+FULL_ITERS = 24000  # invertinggradients.yaml:19; step-lr milestones at 8998 / 15000 / 21015 (common.py:22-27)
+FULL_TWINS = 2      # + the nominal start: three unmodified-reference runs of ~4.5 h each at 2 threads
+FULL_FORCED = (100, 1000, 5000, 9100, 15100, 21100, 23990)  # teacher-forcing targets: early, mid, after each milestone, end
+FULL_DIR = os.path.join(HERE, "_long")  # scratch (git-ignored): partial and finished runs live here
+
+
+def _input_gradient(case, cfg, x):
+    """d total / dx of the reference's objective (restated: objective + TV) at x, fp32 on CPU -- used only to measure how
+    far the REFERENCE's own step direction moves when x moves by a few ulp."""
+    from oracle import restate
+
+    labels = case.shared_data[0]["metadata"]["labels"]
+    regs = cfg.regularization if cfg.regularization is not None else {}
+    x = x.detach().clone().requires_grad_(True)
+    loss = case.loss_fn(case.model(x), labels)
+    g = torch.autograd.grad(loss, tuple(case.model.parameters()), create_graph=True)
+    value = restate.gradient_objective(cfg.objective.type, g, case.shared_data[0]["gradients"], cfg.objective)
+    if "total_variation" in regs:
+        value = value + restate.total_variation(x, **regs["total_variation"])
+    (gx,) = torch.autograd.grad(value, x)
+    return float(value.detach()), gx
+
+
+def _resnet18_full_worker(idx, out_path, threads=2, iters=FULL_ITERS, forced=FULL_FORCED):
+    """One full-horizon run of the unmodified reference (optimization_based_attack.py:110-143) on ResNet-18 / 224 x 224.
+
+    The nominal run (idx 0) additionally records, at the teacher-forcing targets, the candidate x_k the closure was
+    evaluated at, the raw d total/dx that reached ``candidate.grad`` (tensor hook on the leaf) and the map after
+    ``candidate.grad.sign_()`` (:181-182) -- by wrapping the bound ``_compute_objective`` of the attacker INSTANCE from
+    outside; no reference file is touched.  A partial file is rewritten every 500 iterations."""
+    from breaching_amd.cases import build_case, parameter_checksum, psnr
+
+    torch.set_num_threads(threads)
+    breaching = import_reference()
+    case = build_case("resnet18", "ImageNet", 1)
+    cfg = _cfg("invertinggradients", [f"optim.max_iterations={iters}", "optim.callback=1000"])
+    x0 = long_start(case.data_cfg, idx)
+    want = set()
+    if idx == 0:
+        for k in forced:
+            want.update(range(k, min(k + 3, iters)))
+    setup = dict(device=torch.device("cpu"), dtype=torch.float)
+    attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, setup)
+    inner_compute = attacker._compute_objective
+    rec_x, rec_raw, rec_sign = {}, {}, {}
+    state = dict(hooked=None, it=-1, stats=None)
+    import time as _time
+
+    t_start = _time.time()
+
+    def wrapped_compute(candidate, labels, rec_model, optimizer, shared_data, iteration):
+        closure = inner_compute(candidate, labels, rec_model, optimizer, shared_data, iteration)
+        if state["hooked"] is not candidate:
+            state["hooked"] = candidate
+
+            def grab(grad):
+                if state["it"] in want:
+                    rec_raw[state["it"]] = grad.detach().clone()
+
+            candidate.register_hook(grab)
+
+        def spy_closure():
+            state["it"] = iteration
+            if iteration in want:
+                rec_x[iteration] = candidate.detach().clone()
+            value = closure()
+            if iteration in want:
+                rec_sign[iteration] = candidate.grad.detach().clone()
+            return value
+
+        if iteration % 500 == 0 and iteration > 0:
+            print(f"  run {idx}: iteration {iteration}, {(_time.time() - t_start) / iteration:.3f} s/it", flush=True)
+        return spy_closure
+
+    attacker._compute_objective = wrapped_compute
+    torch.manual_seed(7)
+    shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+    rec, stats = attacker.reconstruct(case.server_payload, shared, {}, initial_data=x0)
+    data = rec["data"].detach()
+    out = dict(history=np.asarray(stats["Trial_0_Val"], dtype=np.float64), opt_value=np.float64(stats["opt_value"]),
+               psnr=np.float64(psnr(data, case.true_user_data["data"], case.data_cfg)),
+               rec_mean=np.float64(data.double().mean()), rec_std=np.float64(data.double().std()),
+               seconds=np.float64(_time.time() - t_start), threads=np.int64(threads))
+    if idx == 0:
+        out.update(rec=data[..., :32, :32].numpy(), model_checksum=np.float64(parameter_checksum(case.model)),
+                   labels=rec["labels"].numpy())
+        np.savez(out_path + ".raw.npz", **out, **{f"x_{k}": v.numpy() for k, v in rec_x.items()},
+                 **{f"g_{k}": v.numpy() for k, v in rec_raw.items()}, **{f"s_{k}": v.numpy() for k, v in rec_sign.items()})
+        ks, xs, gs, ss, sens_kept, agree_kept, wagree_kept = [], [], [], [], [], [], []
+        gen = torch.Generator().manual_seed(99)
+        for k in forced:
+            group = [j for j in range(k, k + 3) if j in rec_x]
+            sens = _kink_sensitivity(case, cfg, [rec_x[j] for j in group], trials=2)
+            j = group[int(np.argmin(sens))]
+            # the reference's own step-direction reproducibility at x_j: sign agreement of d total/dx between x_j and
+            # x_j moved by <= 16 ulp (plain fraction of pixels, and weighted by |g|)
+            base_val, base_g = _input_gradient(case, cfg, rec_x[j])
+            agree, wagree = [], []
+            for _ in range(3):
+                _, g2 = _input_gradient(case, cfg, _ulp_perturb(rec_x[j], 16, gen))
+                same = (torch.sign(g2) == torch.sign(base_g)).double()
+                agree.append(float(same.mean()))
+                wagree.append(float((same * base_g.abs().double()).sum() / base_g.abs().double().sum()))
+            print(f"  forced target {k}: sensitivities {sens} -> keep {j}; twin sign agreement {agree} weighted {wagree}; "
+                  f"restated-vs-hook sign agreement {float((torch.sign(base_g) == rec_sign[j]).double().mean()):.6f}", flush=True)
+            ks.append(j), xs.append(rec_x[j].numpy()), gs.append(rec_raw[j].numpy()), ss.append(rec_sign[j].numpy().astype(np.int8))
+            sens_kept.append(float(np.min(sens))), agree_kept.append(min(agree)), wagree_kept.append(min(wagree))
+        out.update(forced_k=np.asarray(ks, dtype=np.int64), forced_x=np.stack(xs).astype(np.float32),
+                   forced_grad=np.stack(gs).astype(np.float32), forced_sign=np.stack(ss),
+                   forced_sensitivity=np.asarray(sens_kept), forced_twin_sign_agreement=np.asarray(agree_kept),
+                   forced_twin_weighted_sign_agreement=np.asarray(wagree_kept))
+    np.savez(out_path, **out)
+
+
+def golden_resnet18_24k(parallel=3):
+    """BASELINE configs[1] at the horizon the config states (24 000 iterations): the nominal start + FULL_TWINS starts
+    <= 16 ulp away, each the unmodified reference on CPU.  Finished runs found in oracle/_long/ are kept, so the step can
+    be re-entered; `--full-worker IDX OUT` runs one of them in the foreground."""
+    import subprocess
+    import time
+
+    os.makedirs(FULL_DIR, exist_ok=True)
+    pending = [i for i in range(FULL_TWINS + 1) if not os.path.exists(os.path.join(FULL_DIR, f"run{i}.npz"))]
+    running = {}
+    while pending or running:
+        while pending and len(running) < parallel:
+            idx = pending.pop(0)
+            path = os.path.join(FULL_DIR, f"run{idx}.npz")
+            log = open(os.path.join(FULL_DIR, f"run{idx}.log"), "w")
+            running[idx] = subprocess.Popen([sys.executable, "-m", "oracle.make_golden", "--full-worker", str(idx), path],
+                                            cwd=ROOT, stdout=log, stderr=subprocess.STDOUT)
+            print(f"  started 24k run {idx}", flush=True)
+        for idx, proc in list(running.items()):
+            if proc.poll() is not None:
+                if proc.returncode != 0:
+                    raise RuntimeError(f"24k run {idx} failed")
+                del running[idx]
+                print(f"  24k run {idx} finished", flush=True)
+        time.sleep(10)
+    assemble_resnet18_24k()
+
+
+def assemble_resnet18_24k():
+    main = dict(np.load(os.path.join(FULL_DIR, "run0.npz")))
+    twins = [np.load(os.path.join(FULL_DIR, f"run{i}.npz")) for i in range(1, FULL_TWINS + 1)
+             if os.path.exists(os.path.join(FULL_DIR, f"run{i}.npz"))]
+    main["history"] = main["history"].astype(np.float32)  # the reference's values ARE fp32 (.item() of an fp32 scalar)
+    main.update(twin_history=np.stack([t["history"] for t in twins]).astype(np.float32),
+                twin_psnr=np.asarray([t["psnr"] for t in twins]), twin_opt_value=np.asarray([t["opt_value"] for t in twins]),
+                twin_rec_mean=np.asarray([t["rec_mean"] for t in twins]), twin_rec_std=np.asarray([t["rec_std"] for t in twins]),
+                iterations=np.int64(len(main["history"])), twin_seed=np.int64(LONG_SEED))
+    np.savez_compressed(os.path.join(GOLDEN, "attack_resnet18_24k.npz"), **main)
+
+
 def golden_seethrough():
     from breaching_amd.cases import build_case, initial_candidate
 
@@ -792,18 +947,27 @@ STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_sc
              resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
              variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg, multiquery=golden_multiquery,
              resnet18_long=golden_resnet18_long, seethrough_b8=golden_seethrough_b8, tag_bert_base=golden_tag_bert_base,
-             pearlmutter=golden_pearlmutter)
-SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base")  # hours of CPU: only run when asked for by name
+             pearlmutter=golden_pearlmutter, resnet18_24k=golden_resnet18_24k)
+SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base", "resnet18_24k")  # hours of CPU: only run when asked for by name
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
     parser.add_argument("--only", default=None)
     parser.add_argument("--long-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
+    parser.add_argument("--full-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
+    parser.add_argument("--full-iters", type=int, default=None, help="(testing the generator) shorter horizon")
     args = parser.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     if args.long_worker is not None:
         _resnet18_long_worker(int(args.long_worker[0]), args.long_worker[1])
+        sys.exit(0)
+    if args.full_worker is not None:
+        if args.full_iters:
+            n = args.full_iters
+            _resnet18_full_worker(int(args.full_worker[0]), args.full_worker[1], iters=n, forced=(2, n // 2, n - 4))
+        else:
+            _resnet18_full_worker(int(args.full_worker[0]), args.full_worker[1])
         sys.exit(0)
     for name, fn in STEPS.items():
         if (args.only is None and name not in SLOW_STEPS) or args.only == name:
