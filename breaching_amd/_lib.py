@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from . import build as _build
 
 # ---- constants mirrored from include/breach_hip.h (checked against the library in tests) -------------------------
-BH_ABI_VERSION = 4
+BH_ABI_VERSION = 5
 BH_GM_CHUNK = 4096
 BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
@@ -88,10 +88,9 @@ _PROTOTYPES = {
     "bh_gm_fwd": (
         c_int,
         [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p,
-         c_void_p, c_void_p, c_void_p],
+         c_int32, c_void_p, c_void_p, c_void_p],
     ),
-    "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32)]),
-    "bh_gm_set_rows_cap": (c_int32, [c_int32]),
+    "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32), c_int32]),
     "bh_gm_finalize": (
         c_int,
         [c_int32, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -120,16 +119,13 @@ _PROTOTYPES = {
     "bh_bn_bwd_accumulate": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bh_bn_eval_fwd": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
     "bh_bn_eval_slabs": (c_int32, [c_int32, c_int32, c_int32]),
-    "bh_bn_eval_bwd": (c_int, [c_void_p] * 9 + [c_int32, c_int32, c_int32, c_void_p]),
+    "bh_bn_eval_bwd": (c_int, [c_void_p] * 11 + [c_int32, c_int32, c_int32, c_void_p]),
     "bh_bn_eval_bwd_bwd": (c_int, [c_void_p] * 12 + [c_int32, c_int32, c_int32, c_void_p]),
     "bh_ln_fwd": (c_int, [c_void_p] * 6 + [c_int32, c_int32, ctypes.c_float, c_void_p]),
     "bh_ln_bwd": (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_void_p]),
     "bh_ln_bwd_bwd": (c_int, [c_void_p] * 12 + [c_int32, c_int32, c_void_p]),
-    "bh_bn_set_grid_cap": (c_int, [c_int32]),
-    "bh_bn_set_finalize_block": (c_int, [c_int32]),
-    "bh_bn_set_load_depth": (c_int, [c_int32]),
-    "bh_bn_sums": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
-    "bh_bn_finalize": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bh_bn_sums": (c_int, [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p]),
+    "bh_bn_finalize": (c_int, [c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "bh_bn_bwd": (
         c_int,
         [c_int32, POINTER(c_void_p), POINTER(c_int32), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -73,6 +73,9 @@ class HipOptimizationAttacker:
             for key in regs.keys():
                 if regs[key].scale > 0:
                     self.regularizers.append(regularizer_lookup[key](self.setup, **regs[key]))
+        for reg in self.regularizers:  # kernel D tuning (measurements only): launch arguments carried by the plan
+            if hasattr(reg, "tuning"):
+                reg.tuning = {name: int(_cfg_get(self.cfg.impl, f"bn_{name}") or 0) for name in ("grid_cap", "load_depth", "finalize_block")}
 
         # optimization_based_attack.py:42-48
         augs = _cfg_get(self.cfg, "augmentations")
@@ -165,14 +168,18 @@ class HipOptimizationAttacker:
             except KeyboardInterrupt:
                 print("Trial procedure manually interruped.")
             if pool is not None:
+                t_wait = time.perf_counter()
                 pool.expect("trials_done")  # a crashed worker raises here instead of hanging the selection collective
+                pool.timing["trials_wait_s"] = round(time.perf_counter() - t_wait, 4)
                 pool.broadcast(("go",))
             before_select = getattr(self, "_before_select", None)
             if before_select is not None:
                 before_select()
             stats["execution_trials"] = dict(self._trial_execution)  # merged over the ranks with the loss histories
+            t_select = time.perf_counter()
             optimal = self._select_optimal_reconstruction(local_solutions, local_scores, stats, shard)
             if pool is not None:
+                pool.timing["select_s"] = round(time.perf_counter() - t_select, 4)
                 pool.finish()
         except BaseException:
             # A failure on any rank between `submit` and the last `ok` -- a worker's error report, or this rank's own trials
@@ -867,13 +874,30 @@ def _vector_ready(t, hw):
     return t
 
 
+def _under_functorch(x):
+    """True while a torch.func transform (vmap / grad / jvp ...) is active or `x` is one of its wrapper tensors.  The custom
+    autograd Functions of kernels E / F carry no functorch rules (no setup_context / vmap staticmethods) and support exactly
+    the two autograd orders the attack uses: under a transform the modules take the torch formulation instead."""
+    try:
+        from torch._C._functorch import is_functorch_wrapped_tensor, peek_interpreter_stack
+
+        return bool(is_functorch_wrapped_tensor(x)) or peek_interpreter_stack() is not None
+    except Exception:  # private API moved: be conservative only about what we can see
+        return False
+
+
 class _EvalBNFunction(torch.autograd.Function):
     """y = x * s_c + t_c of an eval-mode BatchNorm2d as ONE launch (bh_bn_eval_fwd); its backward is `_EvalBNGradFunction`, one
     launch again and itself differentiable -- the attack needs the derivative of the first-order pass (objectives.py:40-46
-    under create_graph=True, then optimization_based_attack.py:160)."""
+    under create_graph=True, then optimization_based_attack.py:160).
+
+    With `tap` (a DeepInversion tap of this layer, priors._BnInputTap) the node has a second, 0-dim output: the token through
+    which the prior's statistic node sends back d objective / d total.  When that token gradient arrives together with gy,
+    the backward launch adds the prior's term gout * (A_c + B_c * x) to gx (it reads x anyway): the prior's backward costs
+    no launch and no traffic of its own (regularizers.py:222-227 / deepinversion.py:93-103, math only)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, inv_std, mean_inv, stats=None):
+    def forward(ctx, x, weight, bias, inv_std, mean_inv, stats=None, tap=None):
         """`stats`: fp64 view of 2 * C * S words that receives sum(x), sum(x^2) per (channel, slab) -- kernel D's input."""
         lib = _lib.load()
         B, C = x.shape[0], x.shape[1]
@@ -887,21 +911,40 @@ class _EvalBNFunction(torch.autograd.Function):
         # the INPUT itself is saved (not the detached kernel view): the backward below is differentiable with respect to it
         ctx.save_for_backward(x, weight, inv_std, mean_inv)
         ctx.has_bias = bias is not None
-        return y
+        ctx.tap = None
+        if tap is None:
+            return y
+        ctx.tap = (tap.record, tap.layer)  # the record of THIS pass: its coefficients are what the backward applies
+        ctx.set_materialize_grads(False)
+        return y, x.new_empty(())
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, g_token=None):
         x, weight, inv_std, mean_inv = ctx.saved_tensors
-        gx, gw, gb = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv)
-        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None
+        if g_token is None or ctx.tap is None:
+            if gy is None:
+                return None, None, None, None, None, None, None
+            gx, gw, gb = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv)
+        else:
+            if torch.is_grad_enabled():
+                raise NotImplementedError("The DeepInversion term fused into the BatchNorm backward supports no create_graph "
+                                          "pass through it (set BREACH_HIP_BN_FUSED_TAP=0).")
+            record, layer = ctx.tap
+            _, coef_ptr = record.layer_coefficients(layer)
+            if gy is None:
+                gy = torch.zeros_like(x)
+            gout = g_token.detach().reshape(1).to(torch.float32)
+            gx, gw, gb = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv, (coef_ptr, gout, record.coef))
+        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None, None
 
 
 class _EvalBNGradFunction(torch.autograd.Function):
     """(gy, x, weight) -> (gx, gw, gb) in one launch (bh_bn_eval_bwd); backward = the derivative of that map in one launch
-    (bh_bn_eval_bwd_bwd).  PyTorch's decomposition of the same three orders is ~35 launches per layer."""
+    (bh_bn_eval_bwd_bwd).  PyTorch's decomposition of the same three orders is ~35 launches per layer.  `tap` = (address of
+    the layer's (A_c, B_c) pairs, gout, owner of that memory): gx additionally receives gout * (A_c + B_c * x)."""
 
     @staticmethod
-    def forward(ctx, gy, x, weight, inv_std, mean_inv):
+    def forward(ctx, gy, x, weight, inv_std, mean_inv, tap=None):
         lib = _lib.load()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
@@ -912,12 +955,14 @@ class _EvalBNGradFunction(torch.autograd.Function):
         gb = torch.empty(C, dtype=torch.float32, device=x.device)
         slabs = lib.bh_bn_eval_slabs(B, C, hw)
         ws = torch.empty(2 * C * slabs, dtype=torch.float64, device=x.device) if slabs > 1 else None
+        coef_ptr, gout = (tap[0], _lib.ptr(tap[1])) if tap is not None else (_lib.ptr(None), _lib.ptr(None))
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_bwd(_lib.ptr(gyk), _lib.ptr(xk), _lib.ptr(weight), _lib.ptr(inv_std), _lib.ptr(mean_inv),
-                                          _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), B, C, hw,
+                                          _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), coef_ptr, gout, B, C, hw,
                                           _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd")
         ctx.save_for_backward(gyk, xk, weight, inv_std, mean_inv)
         ctx.set_materialize_grads(False)
+        ctx.had_tap = tap is not None
         return gx, gw, gb
 
     @staticmethod
@@ -926,7 +971,9 @@ class _EvalBNGradFunction(torch.autograd.Function):
         lib = _lib.load()
         gy, x, weight, inv_std, mean_inv = ctx.saved_tensors
         if ggx is None and ggw is None and ggb is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
+        if ctx.had_tap:
+            raise NotImplementedError("No derivative of the BatchNorm backward with the DeepInversion term fused in.")
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         ggx = None if ggx is None else ggx.to(torch.float32).contiguous()
@@ -936,7 +983,7 @@ class _EvalBNGradFunction(torch.autograd.Function):
         d_x = torch.empty_like(x) if (ctx.needs_input_grad[1] and ggw is not None) else None
         d_w = torch.empty(C, dtype=torch.float32, device=x.device) if (weight is not None and ctx.needs_input_grad[2] and ggx is not None) else None
         if d_gy is None and d_x is None and d_w is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         if ggx is not None and hw % 4 == 0 and ggx.data_ptr() % 16:
             ggx = ggx.clone()
         slabs = lib.bh_bn_eval_slabs(B, C, hw)
@@ -945,7 +992,7 @@ class _EvalBNGradFunction(torch.autograd.Function):
             _lib.check(lib.bh_bn_eval_bwd_bwd(_lib.ptr(ggx), _lib.ptr(ggw), _lib.ptr(ggb), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight),
                                               _lib.ptr(inv_std), _lib.ptr(mean_inv), _lib.ptr(d_gy), _lib.ptr(d_x), _lib.ptr(d_w),
                                               _lib.ptr(ws), B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd_bwd")
-        return d_gy, d_x, d_w, None, None
+        return d_gy, d_x, d_w, None, None, None
 
 
 class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
@@ -961,8 +1008,14 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
     eval_mode = "hip"
 
     def _runs_on_hip(self, x):
-        return (not self.training and self.running_mean is not None and self.running_var is not None and x.dim() == 4
-                and self.eval_mode == "hip" and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0)
+        """Kernel E takes fp32 [B, C, H, W] ROCm activations within its index range (B * HW < 2^31, numel < 2^40), outside
+        torch.func transforms; everything else runs the torch formulation below (same values, more launches)."""
+        if not (not self.training and self.running_mean is not None and self.running_var is not None and x.dim() == 4
+                and self.eval_mode == "hip" and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0):
+            return False
+        if x.shape[0] * x.shape[2] * x.shape[3] >= 2 ** 31 or x.numel() >= 2 ** 40:
+            return False
+        return not _under_functorch(x)
 
     def accepts_stats_sink(self, x):
         """True when the coming forward of `x` will go through kernel E and can fill a per-(channel, slab) statistics buffer
@@ -971,11 +1024,20 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
 
     def forward(self, x):
         sink = self.__dict__.pop("_bn_stats_sink", None)  # set by a DeepInversion tap for this one call
+        tap = self.__dict__.pop("_bn_tap", None)           # likewise: the tap whose token this forward has to emit
+        if tap is not None and not self._runs_on_hip(x):   # (the tap asked `accepts_stats_sink` on the same x: not reached)
+            from .priors import _BnTap
+
+            x, tap.token = _BnTap.apply(x, tap.record, tap.layer)
+            tap.x, tap.live, tap.in_producer, tap = x.detach(), x, False, None
         if self.training or self.running_mean is None or self.running_var is None or x.dim() != 4:
             return super().forward(x)
         inv_std, mean_inv = self._frozen_statistics()
         if self._runs_on_hip(x):
-            return _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv, sink)
+            if tap is None:
+                return _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv, sink)
+            y, tap.token = _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv, sink, tap)
+            return y
         if self.weight is not None:
             scale = self.weight * inv_std
             shift = -(self.weight * mean_inv)
@@ -1112,7 +1174,7 @@ class _HipLayerNorm(torch.nn.LayerNorm):
 
     def forward(self, x):
         if (len(self.normalized_shape) == 1 and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0
-                and x.shape[-1] == self.normalized_shape[0]):
+                and x.shape[-1] == self.normalized_shape[0] and x.numel() < 2 ** 31 and not _under_functorch(x)):
             return _LayerNormFunction.apply(x, self.weight, self.bias, self.eps)
         return super().forward(x)
 
@@ -1161,22 +1223,30 @@ def graph_replay_enabled(cfg):
 
 
 def graph_replay_policy(cfg):
-    """"on" (default: a failed capture raises -- eager launches are 2.4x slower and nobody asked for them), "auto"
-    (a failed capture logs a warning and the trial continues with eager launches; `stats["execution"]` says so), or "off".
-    Set by cfg.impl.hip_graph (True / "auto" / False) or BREACH_HIP_GRAPH (1 / auto / 0)."""
+    """"auto" (default: a failed capture logs a warning, the trial continues with eager HIP launches -- the reference attacks
+    arbitrary models, and one with a host synchronisation or a data-dependent shape in its forward cannot be captured --
+    and `stats["execution"]` / `attacker.last_trial_execution` say so), "required" (a failed capture raises: eager launches
+    are 2.4x slower; the test suite and bench.py run in this mode so that a fall-back can never pass silently), or "off".
+    Set by cfg.impl.hip_graph (True / "auto" / "required" / False) or BREACH_HIP_GRAPH (1 / auto / required / 0);
+    BREACH_HIP_GRAPH_STRICT=1 turns every "auto" into "required" and leaves "off" alone (test suites)."""
     import os
 
     flag = os.environ.get("BREACH_HIP_GRAPH")
     if flag is None:
         flag = _cfg_get(cfg.impl, "hip_graph", True)
     if flag is None:
-        return "on"
-    if isinstance(flag, str):
+        policy = "auto"
+    elif isinstance(flag, str):
         flag = flag.strip().lower()
-        if flag == "auto":
-            return "auto"
-        return "off" if flag in ("0", "false", "off", "no") else "on"
-    return "on" if bool(flag) else "off"
+        if flag in ("required", "require", "strict"):
+            policy = "required"
+        else:
+            policy = "off" if flag in ("0", "false", "off", "no") else "auto"
+    else:
+        policy = "auto" if bool(flag) else "off"
+    if policy == "auto" and os.environ.get("BREACH_HIP_GRAPH_STRICT", "0").strip().lower() not in ("", "0", "false", "off", "no"):
+        policy = "required"
+    return policy
 
 
 class FusedTrial:
@@ -1308,13 +1378,14 @@ class FusedTrial:
         except Exception as exc:
             self.graph, self.use_graph, self.graph_failed = None, False, repr(exc)
             torch.cuda.synchronize(device)
-            if self.graph_policy != "auto":
+            if self.graph_policy == "required":
                 raise RuntimeError(
-                    f"hipGraph capture of the attack iteration failed ({exc!r}). Set cfg.impl.hip_graph='auto' (or "
-                    "BREACH_HIP_GRAPH=auto) to continue with eager launches instead, or False to never capture."
+                    f"hipGraph capture of the attack iteration failed ({exc!r}) and cfg.impl.hip_graph / BREACH_HIP_GRAPH is "
+                    "'required'. With 'auto' (the default) the trial continues with eager launches; False never captures."
                 ) from exc
-            # "auto": stay on the eager HIP path; never leave the GPU
-            log.warning(f"hipGraph capture of the attack iteration failed ({exc!r}); continuing with eager launches.")
+            # "auto": stay on the eager HIP path; never leave the GPU.  Visible to callers in stats["execution"]["trials"].
+            log.warning(f"hipGraph capture of the attack iteration failed ({exc!r}); continuing with eager launches "
+                        "(about 2.4x slower).  cfg.impl.hip_graph='required' turns this into an error.")
 
     def _enqueue_iteration(self):
         lib, att, device = self.lib, self.attacker, self.device

@@ -134,12 +134,23 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
                                                              const float* __restrict__ weight, const float* __restrict__ inv_std,
                                                              const float* __restrict__ mean_inv, float* __restrict__ gx,
                                                              float* __restrict__ gw, float* __restrict__ gb,
-                                                             double* __restrict__ part, int B, int C, int HW, int S, int narrow) {
+                                                             double* __restrict__ part, const float* __restrict__ tap_coef,
+                                                             const float* __restrict__ tap_gout, int B, int C, int HW, int S,
+                                                             int narrow) {
   __shared__ double lds[bh::kWavesPerBlock * 2];
   const ChannelWalk w = channel_of(C, S, narrow != 0);
   double v[2] = {0.0, 0.0};  // sum gy, sum gy * x
   if (w.active) {
     const float s = (weight ? weight[w.c] : 1.f) * inv_std[w.c];
+    // DeepInversion tap (kernel D's backward riding in this launch): gx += g * (A_c + B_c * x), the term rounded exactly as
+    // bn_bwd_acc_kernel rounds it (fmaf(g * B_c, x, g * A_c)) and then added
+    float ta = 0.f, tb = 0.f;
+    if (tap_coef) {
+      const float2 ab = reinterpret_cast<const float2*>(tap_coef)[w.c];
+      const float g0 = tap_gout ? tap_gout[0] : 1.f;
+      ta = g0 * ab.x;
+      tb = g0 * ab.y;
+    }
     const bool vec = (HW & 3) == 0;
     uint32_t unit, v0, v1;
     slab_range(B, HW, S, w.slab, vec, unit, v0, v1);
@@ -151,7 +162,13 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
       const size_t at = (size_t)b * cstride + cbase + j;
       if (vec) {
         const float4 g = reinterpret_cast<const float4*>(gy)[at], q = reinterpret_cast<const float4*>(x)[at];
-        if (gx) reinterpret_cast<float4*>(gx)[at] = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+        if (gx) {
+          if (tap_coef)
+            reinterpret_cast<float4*>(gx)[at] = make_float4(g.x * s + fmaf(tb, q.x, ta), g.y * s + fmaf(tb, q.y, ta),
+                                                            g.z * s + fmaf(tb, q.z, ta), g.w * s + fmaf(tb, q.w, ta));
+          else
+            reinterpret_cast<float4*>(gx)[at] = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+        }
         a0 += (g.x + g.y) + (g.z + g.w);
         a1 = fmaf(g.x, q.x, a1);
         a1 = fmaf(g.y, q.y, a1);
@@ -159,10 +176,10 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
         a1 = fmaf(g.w, q.w, a1);
         cnt += 4;
       } else {
-        const float g = gy[at];
-        if (gx) gx[at] = g * s;
+        const float g = gy[at], q = x[at];
+        if (gx) gx[at] = tap_coef ? g * s + fmaf(tb, q, ta) : g * s;
         a0 += g;
-        a1 = fmaf(g, x[at], a1);
+        a1 = fmaf(g, q, a1);
         cnt += 1;
       }
       if (cnt >= 32) {  // at most 32 values per fp32 accumulator
@@ -307,8 +324,10 @@ int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const
 }
 
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
-                   float* gw, float* gb, double* workspace, int32_t B, int32_t C, int32_t HW, void* stream) {
+                   float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, int32_t B, int32_t C,
+                   int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || gy == nullptr) return BH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(tap_coef) & 7u) != 0 || (tap_coef != nullptr && gx == nullptr)) return BH_EINVAL;
   if ((HW & 3) == 0 &&
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15u) != 0)
     return BH_EINVAL;
@@ -317,7 +336,7 @@ int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const f
   if (S > 1 && workspace == nullptr) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, gy, x, weight, inv_std, mean_inv, gx, gw, gb, workspace,
-                     B, C, HW, S, narrow);
+                     tap_coef, tap_gout, B, C, HW, S, narrow);
   if (S > 1 && (gw != nullptr || gb != nullptr))
     hipLaunchKernelGGL(bn_eval_combine_kernel<2>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, workspace, inv_std,
                        mean_inv, gw, gb, C, S);

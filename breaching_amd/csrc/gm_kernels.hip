@@ -395,11 +395,13 @@ LaunchEvents group_events(void* ev_start, void* ev_stop, bool first, bool last) 
 // Persistent-grid size for a launch group of n chunks: every workgroup gets the same number of chunks (+-1) and the
 // whole grid is resident at once.  Cap 512 (two workgroups per CU, 8 x 16 B loads in flight per thread) measured fastest
 // or equal at every BASELINE size: BERT-base 109.7 us vs 117.6 us at 2048, ResNet-50 32.0 vs 33.0, ResNet-18 17.5 = 17.5.
-int g_rows_cap = BH_GM_DEFAULT_ROWS;
+// The cap is a launch argument (0 = BH_GM_DEFAULT_ROWS): the library keeps no mutable tuning state.
+bool rows_cap_ok(int32_t cap) { return cap >= 0 && cap <= BH_GM_MAX_ROWS; }
 
-int group_rows(int n_chunks_in_group) {
+int group_rows(int n_chunks_in_group, int32_t rows_cap) {
   if (n_chunks_in_group <= 0) return 0;
-  const int rounds = (n_chunks_in_group + g_rows_cap - 1) / g_rows_cap;
+  const int cap = rows_cap > 0 ? rows_cap : BH_GM_DEFAULT_ROWS;
+  const int rounds = (n_chunks_in_group + cap - 1) / cap;
   return (n_chunks_in_group + rounds - 1) / rounds;
 }
 
@@ -463,24 +465,19 @@ int bh_gm_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
   return 0;
 }
 
-int32_t bh_gm_set_rows_cap(int32_t cap) {
-  if (cap < 1 || cap > BH_GM_MAX_ROWS) return BH_EINVAL;
-  g_rows_cap = cap;
-  return 0;
-}
-
-int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin) {
-  if (n_tensors <= 0 || group_chunk_begin == nullptr) return BH_EINVAL;
+int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin, int32_t rows_cap) {
+  if (n_tensors <= 0 || group_chunk_begin == nullptr || !rows_cap_ok(rows_cap)) return BH_EINVAL;
   const int groups = bh_gm_num_groups(n_tensors);
   int rows = 0;
-  for (int g = 0; g < groups; ++g) rows += group_rows(group_chunk_begin[g + 1] - group_chunk_begin[g]);
+  for (int g = 0; g < groups; ++g) rows += group_rows(group_chunk_begin[g + 1] - group_chunk_begin[g], rows_cap);
   return rows;
 }
 
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
-              void* ev_stop) {
+              const float* weights_dev, float tag_scale, double* partials_dev, int32_t rows_cap, void* stream,
+              void* ev_start, void* ev_stop) {
+  if (!rows_cap_ok(rows_cap)) return BH_EINVAL;
   if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
       n_chunks <= 0 || group_chunk_begin == nullptr || partials_dev == nullptr)
     return BH_EINVAL;
@@ -495,7 +492,7 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
   int row_base = 0;
   for (int g = 0; g < groups; ++g) {
     const int begin = group_chunk_begin[g], end = group_chunk_begin[g + 1];
-    const int grid = group_rows(end - begin);
+    const int grid = group_rows(end - begin, rows_cap);
     if (grid <= 0) continue;
     GmPtrs ptrs;
     if (!fill_ptrs(ptrs, rec_ptrs, n_tensors, g)) return BH_EINVAL;

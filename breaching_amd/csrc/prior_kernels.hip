@@ -173,7 +173,7 @@ __device__ __forceinline__ void fast_divmod(uint32_t n, uint32_t d, uint32_t mul
   r = n - q * d;
 }
 
-// Forward items (layer, channel, slab) are streamed by min(n_items, g_bn_grid_cap) workgroups; workgroup w takes items
+// Forward items (layer, channel, slab) are streamed by min(n_items, grid cap) workgroups; workgroup w takes items
 // w, w + G, w + 2G, ... (consecutive workgroups work on consecutive items, i.e. on neighbouring memory).  Measured on the
 // 355.6 MB of ResNet-50 at B = 8 (profiles/r3_kernel_bench.json): G = 512 / 1024 / 2048 / 4096 / one per item =
 // 111 / 74 / 69 / 64 / 62 us -- a persistent grid does not pay here (items are short, 32 KB, and their descriptor fetch
@@ -392,7 +392,7 @@ __device__ __forceinline__ void bn_publish_layer(int layer, int n_layers, double
 }
 
 // Stage 2: one workgroup per layer (see bn_layer_statistic), the workgroup that finishes last adds the layers up into
-// total[0].  THREADS: 256 / 512 / 1024 (bh_bn_set_finalize_block; the statistics of up to 2048 channels stay in registers).
+// total[0].  THREADS: 256 / 512 / 1024 (`block_threads` of bh_bn_finalize; the statistics of up to 2048 channels stay in registers).
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void bn_finalize_kernel(int n_layers, const bh_bn_layer* __restrict__ layers,
                                                          const double* __restrict__ sums,
@@ -406,8 +406,6 @@ __global__ __launch_bounds__(THREADS) void bn_finalize_kernel(int n_layers, cons
   if (threadIdx.x == 0) bn_publish_layer(blockIdx.x, n_layers, value, layer_values, total, counter, counter, 1);
 }
 
-int g_bn_fin_block = BH_BN_DEFAULT_FINALIZE_BLOCK;
-int g_bn_load_depth = 8;
 
 // One workgroup per backward item: BH_BN_TILE consecutive elements of one layer (16-byte vectors when HW % 4 == 0).
 __global__ __launch_bounds__(kBlock) void bn_bwd_kernel(BnPtrs ptrs, const bh_bn_layer* __restrict__ layers,
@@ -525,7 +523,7 @@ void find_divisor(uint32_t d, uint32_t& mul, uint32_t& shr) {
   shr = p - 32u;
 }
 
-int g_bn_grid_cap = BH_BN_DEFAULT_GRID;        // cap of the forward grid (default: none)
+// (the cap of the forward grid, the load depth and the finalize block are launch arguments: no mutable library state)
 
 
 struct BnGeometry {
@@ -663,14 +661,17 @@ bool fill_bn_ptrs(BnPtrs& out, const void* const* x_ptrs, int32_t n_layers, cons
 }  // namespace
 
 int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
-               const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, void* stream) {
+               const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, int32_t grid_cap, int32_t load_depth,
+               void* stream) {
+  if (grid_cap < 0 || grid_cap > (1 << 20) || (load_depth != 0 && load_depth != 4 && load_depth != 8)) return BH_EINVAL;
   if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || x_ptrs == nullptr || hw_host == nullptr || layers_dev == nullptr ||
       fwd_items_dev == nullptr || n_fwd_items <= 0 || n_fwd_items > INT32_MAX || sums_dev == nullptr)
     return BH_EINVAL;
   BnPtrs ptrs;
   if (!fill_bn_ptrs(ptrs, x_ptrs, n_layers, hw_host)) return BH_EINVAL;
-  const int64_t grid = n_fwd_items < g_bn_grid_cap ? n_fwd_items : (int64_t)g_bn_grid_cap;
-  if (g_bn_load_depth == 4)
+  const int64_t cap = grid_cap > 0 ? grid_cap : BH_BN_DEFAULT_GRID;
+  const int64_t grid = n_fwd_items < cap ? n_fwd_items : cap;
+  if (load_depth == 4)
     hipLaunchKernelGGL(bn_sums_kernel<4>, dim3((unsigned int)grid), dim3(kBlock), 0, bh::as_stream(stream), ptrs, layers_dev,
                        fwd_items_dev, (int)n_fwd_items, sums_dev);
   else
@@ -692,27 +693,10 @@ int bh_bn_bwd_accumulate(const float* x, const float* gin, int32_t hw, const bh_
   return bh::launch_status();
 }
 
-int bh_bn_set_load_depth(int32_t depth) {
-  if (depth != 4 && depth != 8) return BH_EINVAL;
-  g_bn_load_depth = depth;
-  return 0;
-}
-
-int bh_bn_set_finalize_block(int32_t threads) {
-  if (threads != 256 && threads != 512 && threads != 1024) return BH_EINVAL;
-  g_bn_fin_block = threads;
-  return 0;
-}
-
-int bh_bn_set_grid_cap(int32_t cap) {
-  if (cap < 1 || cap > (1 << 20)) return BH_EINVAL;
-  g_bn_grid_cap = cap;
-  return 0;
-}
-
 int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double* sums_dev, const float* running_mean,
                    const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
-                   void* counter_dev, void* stream) {
+                   void* counter_dev, int32_t block_threads, void* stream) {
+  if (block_threads != 0 && block_threads != 256 && block_threads != 512 && block_threads != 1024) return BH_EINVAL;
   if (n_layers <= 0 || n_layers > BH_BN_MAX_LAYERS || layers_dev == nullptr || sums_dev == nullptr ||
       running_mean == nullptr || running_var == nullptr || coef_dev == nullptr || layer_values_dev == nullptr ||
       total_dev == nullptr || counter_dev == nullptr)
@@ -722,8 +706,9 @@ int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double
   hipLaunchKernelGGL(bn_finalize_kernel<T>, dim3(n_layers), dim3(T), 0, bh::as_stream(stream), n_layers, layers_dev,    \
                      sums_dev, running_mean, running_var, coef_dev, layer_values_dev, total_dev,                        \
                      static_cast<unsigned int*>(counter_dev))
-  if (g_bn_fin_block == 256) BH_BN_FIN_LAUNCH(256);
-  else if (g_bn_fin_block == 512) BH_BN_FIN_LAUNCH(512);
+  const int threads = block_threads > 0 ? block_threads : BH_BN_DEFAULT_FINALIZE_BLOCK;
+  if (threads == 256) BH_BN_FIN_LAUNCH(256);
+  else if (threads == 512) BH_BN_FIN_LAUNCH(512);
   else BH_BN_FIN_LAUNCH(1024);
 #undef BH_BN_FIN_LAUNCH
   return bh::launch_status();

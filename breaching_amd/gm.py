@@ -38,8 +38,9 @@ class GradientMatchPlan:
     dropped like ``zip`` does at objectives.py:190.
     """
 
-    def __init__(self, gradient_data, n_pairs=None):
+    def __init__(self, gradient_data, n_pairs=None, rows_cap=0):
         lib = _lib.load()
+        self.rows_cap = int(rows_cap)  # workgroups per forward launch group (0 = BH_GM_DEFAULT_ROWS): a plan field, not library state
         tensors = list(gradient_data)
         if n_pairs is not None:
             tensors = tensors[:n_pairs]
@@ -78,7 +79,7 @@ class GradientMatchPlan:
         self._group_bounds = (c_int32 * (n_groups + 1))()
         _lib.check(lib.bh_gm_group_bounds(self.n_tensors, self._chunks_host, self.n_chunks, self._group_bounds), "bh_gm_group_bounds")
         # rows of the forward workspace: one per persistent workgroup (<= 2048 per launch group)
-        self.n_rows = _lib.check(lib.bh_gm_fwd_rows(self.n_tensors, self._group_bounds), "bh_gm_fwd_rows")
+        self.n_rows = _lib.check(lib.bh_gm_fwd_rows(self.n_tensors, self._group_bounds, self.rows_cap), "bh_gm_fwd_rows")
 
         # device copies
         raw = torch.frombuffer(bytearray(bytes(self._chunks_host)), dtype=torch.uint8)
@@ -191,7 +192,7 @@ class GradientMatchPlan:
         ev0, ev1 = self._timed("fwd")
         _lib.check(
             lib.bh_gm_fwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), stream, ev0, ev1),
+                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), self.rows_cap, stream, ev0, ev1),
             "bh_gm_fwd",
         )
         ev0, ev1 = self._timed("fin")
@@ -412,7 +413,14 @@ class HipGradientLoss(torch.nn.Module):
         for plan in self._plans:
             if plan.matches(gradient_data, n_pairs):
                 return plan
-        plan = GradientMatchPlan(gradient_data, n_pairs)
+        rows_cap = 0
+        impl = getattr(self, "cfg_impl", None)
+        if impl is not None:
+            try:
+                rows_cap = int(impl["gm_rows_cap"] or 0)  # tuning (measurements only): workgroups per forward launch group
+            except (KeyError, AttributeError, TypeError):
+                rows_cap = 0
+        plan = GradientMatchPlan(gradient_data, n_pairs, rows_cap=rows_cap)
         self._plans.append(plan)  # one plan per observed list: multi-query / multi-model payloads alternate between them
         return plan
 

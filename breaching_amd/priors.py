@@ -129,7 +129,7 @@ class BnStatPlan:
     """Static state of kernel D for one model: geometry tables of all BatchNorm inputs, packed running statistics,
     layer weights.  Built at the first evaluation of a trial (the input shapes are known only after a forward pass)."""
 
-    def __init__(self, shapes, running_means, running_vars, weights, device):
+    def __init__(self, shapes, running_means, running_vars, weights, device, grid_cap=0, load_depth=0, finalize_block=0):
         import ctypes
         from ctypes import c_float, c_int32, c_int64
 
@@ -139,6 +139,8 @@ class BnStatPlan:
             raise ValueError(f"DeepInversion prior supports 1..{_lib.BH_BN_MAX_LAYERS} BatchNorm layers, got {n}.")
         self.device = device
         self.n_layers = n
+        # tuning arguments of the launches (0 = the library's defaults); fields of the plan, not process-wide state
+        self.grid_cap, self.load_depth, self.finalize_block = int(grid_cap), int(load_depth), int(finalize_block)
         self.shapes = [tuple(s) for s in shapes]
         B = (c_int32 * n)(*[s[0] for s in shapes])
         C = (c_int32 * n)(*[s[1] for s in shapes])
@@ -154,6 +156,7 @@ class BnStatPlan:
         _lib.check(lib.bh_bn_plan_build(n, B, C, self.hw_host, w, layers, fwd, self.n_fwd, bwd, self.n_bwd), "bh_bn_plan_build")
         self.flat_offsets = [layers[i].flat_off for i in range(n)]
         self.sums_offsets = [layers[i].sums_off for i in range(n)]       # in (sum, sum of squares) pairs
+        self.chan_offsets = [layers[i].chan_off for i in range(n)]       # first channel of a layer in the packed (A_c, B_c) array
         self.layer_pairs = [layers[i].C * layers[i].S for i in range(n)]  # pairs of one layer: C x S
         # per layer: first backward item and item count (the table is built layer by layer) -- the per-layer fused
         # backward-accumulate launches address their slice of it
@@ -203,10 +206,10 @@ class _BnStatFunction(torch.autograd.Function):
                 ticket = torch.zeros(1, dtype=torch.int32, device=dev)
             ptrs = plan.pointers(prepared)
             _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
-                                      plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
+                                      plan.n_fwd, _lib.ptr(sums), plan.grid_cap, plan.load_depth, stream), "bh_bn_sums")
             _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
                                           _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
-                                          _lib.ptr(ticket), stream), "bh_bn_finalize")
+                                          _lib.ptr(ticket), plan.finalize_block, stream), "bh_bn_finalize")
         ctx.plan = plan
         ctx.save_for_backward(coef, *prepared)
         ctx.in_shapes = [x.shape for x in xs]
@@ -238,12 +241,30 @@ def accumulate_in_kernel():
 
 
 class _BnTapRecord:
-    """What the taps of one model and the statistic node share during one evaluation: the plan, the coefficient array the
-    finalize kernel wrote, and per layer the activation the tap saw."""
+    """What the taps of one model and the statistic node share during ONE evaluation (one forward pass of the model): the
+    plan and the coefficient array the finalize kernel wrote for that pass.  A fresh record is opened by the first layer's
+    tap of every pass and every tap of the pass keeps its own reference, so a backward through an older (retained) graph
+    applies that pass's A_c / B_c, never a later pass's."""
 
     def __init__(self):
         self.plan = None
         self.coef = None
+        self.seen = set()  # layers whose tap joined this pass
+
+    def layer_coefficients(self, layer):
+        """(plan, address of this layer's C (A_c, B_c) pairs inside the pass's coefficient array) for a backward launch."""
+        plan, coef = self.plan, self.coef
+        if plan is None or coef is None:
+            raise RuntimeError("DeepInversion tap received a gradient without a forward evaluation of the statistic.")
+        return plan, ctypes_offset(coef, 2 * plan.chan_offsets[layer])
+
+
+def fused_tap_enabled():
+    """BREACH_HIP_BN_FUSED_TAP=0 keeps round 3's separate per-layer read-modify-write launch (bh_bn_bwd_accumulate) for
+    before / after profiles; default: the prior's backward rides in kernel E's backward launch of the same layer."""
+    import os
+
+    return os.environ.get("BREACH_HIP_BN_FUSED_TAP", "1") != "0"
 
 
 class _BnTap(torch.autograd.Function):
@@ -266,7 +287,7 @@ class _BnTap(torch.autograd.Function):
         if g_token is None:
             return g_x, None, None
         (x,) = ctx.saved_tensors
-        plan, coef = ctx.record.plan, ctx.record.coef
+        plan, coef = ctx.record.plan, ctx.record.coef  # the record of the pass this tap belongs to
         if plan is None or coef is None:
             raise RuntimeError("DeepInversion tap received a gradient without a forward evaluation of the statistic.")
         lib = _lib.load()
@@ -312,10 +333,10 @@ class _BnStatTokenFunction(torch.autograd.Function):
             if fed_sums is None:
                 ptrs = plan.pointers(xs)
                 _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev),
-                                          plan.n_fwd, _lib.ptr(sums), stream), "bh_bn_sums")
+                                          plan.n_fwd, _lib.ptr(sums), plan.grid_cap, plan.load_depth, stream), "bh_bn_sums")
             _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
                                           _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
-                                          _lib.ptr(ticket), stream), "bh_bn_finalize")
+                                          _lib.ptr(ticket), plan.finalize_block, stream), "bh_bn_finalize")
         record.plan, record.coef = plan, coef
         ctx.n_tokens = len(tokens)
         return total[0]
@@ -347,6 +368,7 @@ class _BnInputTap:
     def __init__(self, module, record, layer, owner=None, model_idx=0):
         self.module, self.record, self.layer = module, record, layer
         self.owner, self.model_idx = owner, model_idx
+        self.in_producer = False  # this pass: the module's own autograd node (kernel E) carries the token, no `_BnTap` node
         self.fed = False   # this pass: the module's own forward kernel writes the layer's channel sums (no bn_sums needed)
         self.x = None      # the activation of the latest forward pass (detached view, what kernel D reads)
         self.token = None  # its token (carries the autograd edge back to the tap)
@@ -361,13 +383,31 @@ class _BnInputTap:
             x = x.contiguous()
         if x.dim() > 2 and x[0, 0].numel() % 4 == 0 and x.data_ptr() % 16:
             x = x.clone()  # 16-byte vector loads need an aligned base
-        tapped, token = _BnTap.apply(x, self.record, self.layer)
-        self.x, self.token, self.live = tapped.detach(), token, tapped
+        if self.owner is not None:
+            # A new pass begins when the current record was already consumed by an evaluation of the statistic, or this
+            # layer was already seen in it (a forward pass the prior was not evaluated on, e.g. trial scoring).
+            record = self.owner._records[self.model_idx]
+            if record.plan is not None or self.layer in record.seen:
+                record = self.owner._records[self.model_idx] = _BnTapRecord()
+            record.seen.add(self.layer)
+            self.record = record
+        accepts = getattr(module, "accepts_stats_sink", None)
+        on_kernel_e = self.owner is not None and callable(accepts) and accepts(x)
+        self.fed = self.in_producer = False
+        if on_kernel_e and accumulate_in_kernel() and fused_tap_enabled():
+            # The module's forward IS one of our autograd nodes: it emits the token itself and its backward launch
+            # (bh_bn_eval_bwd, which reads x anyway) adds the prior's term -- no identity node, no launch of its own.
+            # One-shot attribute, consumed (and `self.token` filled) by that forward.
+            module._bn_tap = self
+            self.x, self.token, self.live = x.detach(), None, None
+            self.in_producer = True
+            tapped = x
+        else:
+            tapped, token = _BnTap.apply(x, self.record, self.layer)
+            self.x, self.token, self.live = tapped.detach(), token, tapped
         # Producer-side statistics: when the module's forward is kernel E, let it write sum(x), sum(x^2) of this layer straight
         # into the prior's sums buffer while it reads x anyway (one-shot attribute, consumed by that forward).
-        self.fed = False
-        accepts = getattr(module, "accepts_stats_sink", None)
-        if self.owner is not None and callable(accepts) and accepts(tapped):
+        if on_kernel_e:
             sink = self.owner._sink_for(self.model_idx, self.layer, tapped)
             if sink is not None:
                 module._bn_stats_sink = sink
@@ -388,6 +428,7 @@ class HipDeepInversion(torch.nn.Module):
         self.first_bn_multiplier = first_bn_multiplier
         self.losses = []
         self._plans = {}
+        self.tuning = {}  # launch arguments of kernel D (grid_cap / load_depth / finalize_block; the attacker copies cfg.impl.bn_*)
         self.ticket_scope = None  # dict owned by a trial (FusedTrial.tickets): one re-zeroed ticket word per model
         self._default_scope = {}  # the same outside the fused loop (generic torch.optim loop, stand-alone use)
 
@@ -411,8 +452,8 @@ class HipDeepInversion(torch.nn.Module):
         for hooks in self.losses:
             for hook in hooks:
                 hook.x = hook.token = hook.live = None
-        for record in getattr(self, "_records", []):
-            record.coef = None
+        # the taps of a pass keep their own reference to that pass's record: a retained graph stays backpropagatable
+        self._records = [_BnTapRecord() for _ in getattr(self, "_records", [])]
 
     def _sums_buffer(self, idx, plan):
         """The per-(channel, slab) sums of model `idx`: one buffer per trial (trials in flight run on different streams and
@@ -446,7 +487,7 @@ class HipDeepInversion(torch.nn.Module):
                     raise RuntimeError("DeepInversion prior needs BatchNorm running statistics (buffers) on the attacked model.")
             weights = [self.scale * (self.first_bn_multiplier if i == 0 else 1.0) for i in range(len(hooks))]
             plan = BnStatPlan(shapes, [h.module.running_mean for h in hooks], [h.module.running_var for h in hooks], weights,
-                              xs[0].device)
+                              xs[0].device, **self.tuning)
             self._plans[idx] = plan
         return plan
 
@@ -456,7 +497,7 @@ class HipDeepInversion(torch.nn.Module):
             if len(hooks) == 0:
                 continue
             xs = [hook.x for hook in hooks]
-            if any(x is None for x in xs):
+            if any(x is None for x in xs) or (accumulate_in_kernel() and any(hook.token is None for hook in hooks)):
                 raise RuntimeError("DeepInversion prior evaluated before a forward pass of the attacked model.")
             plan = self._plan(idx, hooks, xs)
             ticket = None

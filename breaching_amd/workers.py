@@ -35,8 +35,13 @@ import torch
 log = logging.getLogger(__name__)
 
 # Collectives are entered only after every rank reported `trials_done` (see the protocol above), so a rank never waits in
-# one for longer than the others need to get there: seconds.  The same limit bounds the start-up rendezvous.
+# one for longer than the others need to get there: seconds.
 DEFAULT_COLLECTIVE_TIMEOUT = 180.0
+# Start-up is a different matter: spawn, `import torch` on a cold box (1-2 minutes for the first process of a fresh
+# container), RCCL communicator creation over up to 8 GPUs and building the attacker in every worker.  Its own, longer limit
+# (BREACH_HIP_POOL_START_TIMEOUT); exceeding it raises in `TrialWorkerPool.__init__` and the attacker falls back to one GPU
+# (or raises with impl.trial_pool=required).
+DEFAULT_START_TIMEOUT = 600.0
 
 _ACTIVE_POOL = None  # weak reference: a pool dies with the attacker that owns it
 
@@ -91,6 +96,23 @@ def to_cpu(obj):
     return obj
 
 
+def isolate_miopen_user_db(rank):
+    """Give this rank its own MIOpen user database directory unless the user chose one.  On a fresh box every process runs
+    MIOpen's solver search for each convolution configuration on first use and records the result in the user find-db; eight
+    first processes sharing one sqlite file serialise on its lock and time their candidate solvers against each other
+    (profiles/r3_miopen_selection.txt: the search doubles the dispatches of the first iterations).  Must run before the
+    process's first convolution."""
+    if "MIOPEN_USER_DB_PATH" in os.environ:
+        return os.environ["MIOPEN_USER_DB_PATH"]
+    path = os.path.join(os.path.expanduser("~"), ".config", "miopen", f"breach_hip_rank{int(rank)}")
+    try:
+        os.makedirs(path, exist_ok=True)
+    except OSError:
+        return None
+    os.environ["MIOPEN_USER_DB_PATH"] = path
+    return path
+
+
 def requested_devices(cfg, device):
     """Device indices the restarts may use: ``cfg.impl.trial_devices`` / ``BREACH_HIP_TRIAL_DEVICES`` ("all", "0,1,2", or a
     list; an index may repeat to put several ranks on one GPU), default: every visible GPU, the caller's own first."""
@@ -119,6 +141,7 @@ def _worker_main(rank, world, port, backend, device_index, conn, runner_factory,
 
     try:
         conn.send(("booted",))  # the spawn bootstrap unpickled our arguments: the parent may start its own rendezvous
+        isolate_miopen_user_db(rank)
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         if device_index is not None:
@@ -162,11 +185,15 @@ class TrialWorkerPool:
                  drain_timeout=15.0):
         import datetime
 
+        import time
+
         import torch.distributed as dist
         import torch.multiprocessing as mp
 
         if dist.is_initialized():
             raise RuntimeError("TrialWorkerPool needs to own the default process group of the calling process.")
+        t_start = time.perf_counter()
+        self.timing = {}  # pool_start_s here; job_ship_s / trials_wait_s / select_s of the latest job (set by the attacker)
         self.devices = list(devices)
         self.world = len(self.devices)
         if self.world < 2:
@@ -178,7 +205,9 @@ class TrialWorkerPool:
         if collective_timeout is None:
             collective_timeout = float(os.environ.get("BREACH_HIP_COLLECTIVE_TIMEOUT", DEFAULT_COLLECTIVE_TIMEOUT))
         self.collective_timeout = float(collective_timeout)
-        start_timeout = self.collective_timeout if start_timeout is None else float(start_timeout)
+        if start_timeout is None:
+            start_timeout = float(os.environ.get("BREACH_HIP_POOL_START_TIMEOUT", DEFAULT_START_TIMEOUT))
+        self.start_timeout = start_timeout = float(start_timeout)
         self.drain_timeout = float(drain_timeout)
         self.busy = False  # a job is in flight (between submit and the last `ok`)
         self.port = free_port()
@@ -202,8 +231,10 @@ class TrialWorkerPool:
             # in the spawn bootstrap; `_collect` polls `is_alive`, so that is noticed here in a fraction of a second and
             # not after the rendezvous timeout below.
             self.expect("booted", start_timeout)
+            # the group's own timeout is the COLLECTIVE limit on every rank (it bounds the store rendezvous and RCCL's eager
+            # communicator creation too: by now every worker has imported torch and is at the same call)
             dist.init_process_group(backend, rank=0, world_size=self.world,
-                                    timeout=datetime.timedelta(seconds=start_timeout), **kwargs)
+                                    timeout=datetime.timedelta(seconds=self.collective_timeout), **kwargs)
             for message in self._collect(start_timeout):
                 if message[0] != "ready":
                     raise RuntimeError(f"worker failed to start:\n{message[-1]}")
@@ -213,19 +244,27 @@ class TrialWorkerPool:
         self.closed = False
         global _ACTIVE_POOL
         _ACTIVE_POOL = weakref.ref(self)
-        log.info(f"Trial worker pool up: {self.world} ranks on devices {self.devices} ({backend}, collective timeout "
-                 f"{self.collective_timeout:.0f} s).")
+        self.timing["pool_start_s"] = round(time.perf_counter() - t_start, 3)
+        log.info(f"Trial worker pool up in {self.timing['pool_start_s']:.1f} s: {self.world} ranks on devices {self.devices} "
+                 f"({backend}, collective timeout {self.collective_timeout:.0f} s).")
 
     def describe(self):
-        """What a caller gets to see in `stats["trial_pool"]`."""
-        return dict(backend=self.backend, world=self.world, devices=list(self.devices))
+        """What a caller gets to see in `stats["execution"]["pool"]`: the group, and where the wall time outside the trials
+        went -- `pool_start_s` (spawn + imports + communicator + worker attackers; paid by the first call only),
+        `job_ship_s` (host copies of the inputs pickled down the pipes), `trials_wait_s` (rank 0 waiting for the slowest
+        worker after its own trials), `select_s` (all-reduce + broadcast + history gather)."""
+        return dict(backend=self.backend, world=self.world, devices=list(self.devices), **self.timing)
 
     # -- messaging -------------------------------------------------------------------------------------------------
     def submit(self, jobs):
         """`jobs[r - 1]` goes to rank r."""
+        import time
+
+        t0 = time.perf_counter()
         self.busy = True
         for (proc, conn), job in zip(self.workers, jobs):
             conn.send(("job", job))
+        self.timing["job_ship_s"] = round(time.perf_counter() - t0, 4)
 
     def finish(self):
         """Every worker reported `ok`: the job is over."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 4
+#define BH_ABI_VERSION 5
 #define BH_EINVAL (-1)
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -106,13 +106,13 @@ int bh_gm_build_table(int32_t n_tensors, const int64_t* numel, bh_gm_chunk* chun
  * reference: objectives.py:89-95, 133-141, 158-166, 183-196, 233-244, 259-273 (the list reductions). */
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, void* stream, void* ev_start,
-              void* ev_stop);
+              const float* weights_dev, float tag_scale, double* partials_dev, int32_t rows_cap, void* stream,
+              void* ev_start, void* ev_stop);
 /* Rows (= workgroups over all launch groups) bh_gm_fwd writes for this list: chunks are dealt out evenly to at most
- * `rows cap` workgroups per launch group (default BH_GM_DEFAULT_ROWS).  Negative on invalid arguments. */
-int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin);
-/* Tuning knob (process global, host side): cap of workgroups per forward launch group, 1..BH_GM_MAX_ROWS. */
-int32_t bh_gm_set_rows_cap(int32_t cap);
+ * `rows_cap` workgroups per launch group (1..BH_GM_MAX_ROWS; 0 = BH_GM_DEFAULT_ROWS).  The cap is an argument of this
+ * call and of bh_gm_fwd (pass the same value to both): the library holds no mutable tuning state, so two host threads
+ * may use different caps.  Negative on invalid arguments. */
+int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin, int32_t rows_cap);
 /* `ev_start` / `ev_stop` (here and in bh_gm_bwd): optional hipEvent_t handles from bh_event_create.  When given, the
  * launch goes through hipExtLaunchKernelGGL, so the events carry the dispatch's own begin / end timestamps (the
  * completion-signal times rocprofv3 reports) -- no host latency, no marker overhead.  Not usable during stream
@@ -213,30 +213,26 @@ int bh_bn_plan_build(int32_t n_layers, const int32_t* B, const int32_t* C, const
                      bh_bn_layer* layers, bh_bn_item* fwd_items, int64_t n_fwd_items, bh_bn_item* bwd_items,
                      int64_t n_bwd_items);
 
-/* Stage 1: per-channel sum and sum of squares of every layer -- min(n_fwd_items, cap) workgroups stream the forward items
- * (cap = BH_BN_DEFAULT_GRID unless bh_bn_set_grid_cap changed it) -- into sums_dev[2 * n_sum_pairs] doubles (overwritten).  `x_ptrs` / `hw_host`: HOST arrays (device pointers, HW per layer).
+/* Stage 1: per-channel sum and sum of squares of every layer -- min(n_fwd_items, grid_cap) workgroups stream the forward
+ * items -- into sums_dev[2 * n_sum_pairs] doubles (overwritten).  `x_ptrs` / `hw_host`: HOST arrays (device pointers, HW per
+ * layer).  Tuning arguments of this launch (no library state): `grid_cap` 1..2^20 workgroups of the persistent grid
+ * (0 = BH_BN_DEFAULT_GRID); `load_depth` 16-byte loads in flight per thread, 4 or 8 (0 = 8).
  * reference: deepinversion.py:93-96 (mean / biased var of the BN input). */
 int bh_bn_sums(int32_t n_layers, const void* const* x_ptrs, const int32_t* hw_host, const bh_bn_layer* layers_dev,
-               const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, void* stream);
+               const bh_bn_item* fwd_items_dev, int64_t n_fwd_items, double* sums_dev, int32_t grid_cap, int32_t load_depth,
+               void* stream);
 
 #define BH_BN_DEFAULT_FINALIZE_BLOCK 1024
-/* Tuning knob of stage 2 (process wide): threads per layer workgroup, 256 / 512 / 1024. */
-int bh_bn_set_finalize_block(int32_t threads);
-
-/* Tuning knob of stage 1 (process wide): 16-byte loads in flight per thread, 4 or 8 (default 8). */
-int bh_bn_set_load_depth(int32_t depth);
-
-/* Tuning knob of stage 1 (process wide, default BH_BN_DEFAULT_GRID): workgroups of the persistent forward grid. */
-int bh_bn_set_grid_cap(int32_t cap);
 
 /* Stage 2 (one workgroup per layer): mean_c, var_c, r_l, the backward coefficients coef_dev[2 * n_channels] (fp32,
  * 8-byte aligned; d total / d x_l[b,c,hw] = A_c + B_c * x) and total_dev[0] = sum_l weight_l * r_l, added up in layer
  * order by the last workgroup to finish.  `running_mean` / `running_var`: packed per chan_off.  `layer_values_dev`:
- * n_layers doubles of workspace; `counter_dev`: a zeroed uint32 (re-zeroed by the kernel).
+ * n_layers doubles of workspace; `counter_dev`: a zeroed uint32 (re-zeroed by the kernel).  `block_threads`: threads of a
+ * layer's workgroup, 256 / 512 / 1024 (0 = BH_BN_DEFAULT_FINALIZE_BLOCK) -- an argument of the launch, not library state.
  * reference: deepinversion.py:96-101, regularizers.py:222-227. */
 int bh_bn_finalize(int32_t n_layers, const bh_bn_layer* layers_dev, const double* sums_dev, const float* running_mean,
                    const float* running_var, float* coef_dev, double* layer_values_dev, float* total_dev,
-                   void* counter_dev, void* stream);
+                   void* counter_dev, int32_t block_threads, void* stream);
 
 /* Backward of all layers in one launch: grad_flat[flat_off_l + i] = gout * (A_c + B_c * x_l[i]); gout read from
  * *gout_dev (NULL = 1).  grad_flat (16-byte aligned, flat_elems floats) is overwritten. */
@@ -270,9 +266,15 @@ int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const
  * whole order is then ONE launch; otherwise about one per 8 192 elements, at most 64, and the backward orders take a small
  * second launch that adds the per-slab sums in slab order).  `workspace` below: 2 * C * S doubles (may be NULL when S == 1). */
 int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW);
-/* gx = gy * s_c (skipped when gx is NULL); gw_c = inv_std_c * sum(gy * x) - mean_inv_c * sum(gy); gb_c = sum(gy). */
+/* gx = gy * s_c (skipped when gx is NULL); gw_c = inv_std_c * sum(gy * x) - mean_inv_c * sum(gy); gb_c = sum(gy).
+ * `tap_coef` (may be NULL; 8-byte aligned): the C (A_c, B_c) pairs bh_bn_finalize wrote for THIS layer (coef_dev + 2 * chan_off)
+ * and `tap_gout` (device scalar, NULL = 1): the DeepInversion prior's backward of this BatchNorm input rides in the launch --
+ * gx = gy * s_c + gout * (A_c + B_c * x) -- instead of a read-modify-write pass of its own (bh_bn_bwd_accumulate): x is read
+ * here anyway, so the prior's backward costs no traffic on models whose BatchNorm runs through these kernels.
+ * reference: deepinversion.py:93-103 (the statistic whose gradient this is; math only). */
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
-                   float* gw, float* gb, double* workspace, int32_t B, int32_t C, int32_t HW, void* stream);
+                   float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, int32_t B, int32_t C,
+                   int32_t HW, void* stream);
 /* Derivative of bh_bn_eval_bwd for incoming (ggx [B,C,HW], ggw [C], ggb [C]; each may be NULL = zero):
  * d_gy = ggx * s_c + ggw_c * (inv_std_c * x - mean_inv_c) + ggb_c;  d_x = ggw_c * inv_std_c * gy;  d_w_c = inv_std_c * sum(ggx * gy).
  * Outputs may be NULL (not computed). */

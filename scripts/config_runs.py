@@ -25,11 +25,10 @@ if args.only is None and args.per_process:
 # fixed in round 3, see attacker._run_trial_group and profiles/r3_stall_bisect.jsonl.)
 dev = torch.device("cuda:0")
 setup = dict(device=dev, dtype=torch.float)
-# kernel D tuning knobs for same-box A/B profiles (scripts/r3_call10.sh)
-from breaching_amd import _lib as _bh_lib
-for env, setter in (("BN_DEPTH", "bh_bn_set_load_depth"), ("BN_GRID_CAP", "bh_bn_set_grid_cap"), ("BN_FIN_BLOCK", "bh_bn_set_finalize_block")):
-    if env in os.environ:
-        assert getattr(_bh_lib.load(), setter)(int(os.environ[env])) == 0, env
+# kernel D tuning for same-box A/B profiles: since ABI 5 these are launch arguments carried by the plan (cfg.impl.bn_grid_cap /
+# bn_load_depth / bn_finalize_block), not process-wide library state
+BN_TUNING = [f"impl.{key}={os.environ[env]}" for env, key in (("BN_DEPTH", "bn_load_depth"), ("BN_GRID_CAP", "bn_grid_cap"),
+                                                               ("BN_FIN_BLOCK", "bn_finalize_block")) if env in os.environ]
 out = {}
 
 
@@ -64,7 +63,7 @@ if args.only in (None, "2"):
 if args.only in (None, "3"):
     case = build_case("resnet50", "ImageNet", 8, device=dev, gradient_device=dev, provide_buffers=True)
     run(f"configs[2] ResNet-50 ImageNet batch 8 see-through-gradients (+DeepInversion), {args.its} its", case,
-        breaching_amd.get_attack_config("seethroughgradients", [f"optim.max_iterations={args.its}", "optim.callback=100"]), initial_candidate(case.data_cfg, 8))
+        breaching_amd.get_attack_config("seethroughgradients", [f"optim.max_iterations={args.its}", "optim.callback=100", *BN_TUNING]), initial_candidate(case.data_cfg, 8))
 if args.only in (None, "4"):
     case = build_case("resnet18", "ImageNet", 1, device=dev, gradient_device=dev)
     its = 24000 if args.full else 500

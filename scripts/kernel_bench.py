@@ -83,8 +83,7 @@ def gm_case(name, shapes):
     # launch alone / event pair around the finalize launch; burst: back-to-back stage time incl. both launch boundaries
     sweep = {}
     for cap in (128, 256, 384, 512, 768, 1024, 2048):
-        lib.bh_gm_set_rows_cap(cap)
-        p2 = GradientMatchPlan(data)
+        p2 = GradientMatchPlan(data, rows_cap=cap)
         p2.enable_timing()
         for _ in range(30):
             p2.forward(0, rec, 1.0, 0.0, 1e-7, None)
@@ -93,7 +92,6 @@ def gm_case(name, shapes):
         us = burst(lambda: p2.forward(0, rec, 1.0, 0.0, 1e-7, None), reps=40)
         sweep[f"cap{cap}"] = dict(rows=p2.n_rows, fwd_event_us=round(sum(ev) / len(ev), 2), finalize_us=round(sum(fin) / len(fin), 2),
                                   stage_burst_us=round(us, 2))
-    lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
     res["forward_stage_sweep_cosine"] = sweep
     out[f"kernelA_{name}"] = res
 
@@ -158,13 +156,14 @@ total_out = torch.empty(1, device=dev)
 ticket = torch.zeros(1, dtype=torch.int32, device=dev)
 grad_flat = torch.empty(plan.flat_elems, device=dev)
 ptrs = plan.pointers(acts)
+knobs = dict(grid_cap=0, load_depth=0, finalize_block=0)  # launch arguments (0 = library default)
 def d_sums():
     _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev), plan.n_fwd,
-                              _lib.ptr(sums), _lib.current_stream_handle(dev)), "sums")
+                              _lib.ptr(sums), knobs["grid_cap"], knobs["load_depth"], _lib.current_stream_handle(dev)), "sums")
 def d_fin():
     _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
                                   _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total_out),
-                                  _lib.ptr(ticket), _lib.current_stream_handle(dev)), "finalize")
+                                  _lib.ptr(ticket), knobs["finalize_block"], _lib.current_stream_handle(dev)), "finalize")
 def d_fwd():
     d_sums(); d_fin()
 def d_bwd():
@@ -180,14 +179,14 @@ out["kernelD_resnet50_B8"] = dict(layers=len(acts), elements=total, fwd_items=pl
                                        "(burst of back-to-back launches; 355.6 MB read forward, read + written backward)")
 sweep = {}
 for cap in (512, 1024, 2048, 4096, 1 << 20):
-    lib.bh_bn_set_grid_cap(cap)
+    knobs["grid_cap"] = cap
     sweep[str(cap)] = round(burst(d_sums, reps=20, warm=3), 1)
-lib.bh_bn_set_grid_cap(1 << 20)
+knobs["grid_cap"] = 0
 out["kernelD_resnet50_B8"]["sums_us_by_grid_cap"] = sweep
 fin = {}
 for threads in (256, 512, 1024):
-    lib.bh_bn_set_finalize_block(threads)
+    knobs["finalize_block"] = threads
     fin[str(threads)] = dict(finalize_us=round(burst(d_fin, reps=20, warm=3), 1), stage_us=round(burst(d_fwd, reps=20, warm=3), 1))
-lib.bh_bn_set_finalize_block(1024)
+knobs["finalize_block"] = 0
 out["kernelD_resnet50_B8"]["finalize_by_block_threads"] = fin
 print(json.dumps(out, indent=1))

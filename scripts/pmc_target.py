@@ -38,10 +38,10 @@ if args.size == "bn":
     st = _lib.current_stream_handle(dev)
     for _ in range(args.reps):
         _lib.check(lib.bh_bn_sums(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.fwd_dev), plan.n_fwd,
-                                  _lib.ptr(sums), st), "sums")
+                                  _lib.ptr(sums), 0, 0, st), "sums")
         _lib.check(lib.bh_bn_finalize(plan.n_layers, _lib.ptr(plan.layers_dev), _lib.ptr(sums), _lib.ptr(plan.running_mean),
                                       _lib.ptr(plan.running_var), _lib.ptr(coef), _lib.ptr(layer_values), _lib.ptr(total),
-                                      _lib.ptr(ticket), st), "finalize")
+                                      _lib.ptr(ticket), 0, st), "finalize")
         _lib.check(lib.bh_bn_bwd(plan.n_layers, ptrs, plan.hw_host, _lib.ptr(plan.layers_dev), _lib.ptr(plan.bwd_dev), plan.n_bwd,
                                  _lib.ptr(coef), None, _lib.ptr(grad_flat), st), "bwd")
     torch.cuda.synchronize()

@@ -20,6 +20,9 @@ def _restarts_stay_on_one_gpu(request, monkeypatch):
     """On a multi-GPU box `reconstruct` with several restarts starts one worker process per visible GPU by default.  The
     parity tests compare single-device trajectories: pin them (and the scripts they spawn) to the attacker's own GPU, whatever
     the box looks like.  Tests marked `trial_pool` pick their devices themselves."""
+    # The product's default lets a failed hipGraph capture continue with eager launches (visible in stats["execution"]);
+    # in this suite a silent 2.4x slower path must fail the test instead.
+    monkeypatch.setenv("BREACH_HIP_GRAPH_STRICT", "1")  # "auto" -> "required"; cfg.impl.hip_graph=False still means eager
     if request.node.get_closest_marker("trial_pool") is None:
         monkeypatch.setenv("BREACH_HIP_TRIAL_DEVICES", "0")
     else:

@@ -85,7 +85,7 @@ def test_chunk_table_host_helpers(hip_lib):
     assert list(bounds) == [0, _lib.BH_GM_MAX_PTRS, len(many)]
     # invalid arguments are reported, not crashed on
     assert hip_lib.bh_gm_table_size(-1, arr, byref(n_chunks), byref(flat)) == -1
-    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, None, None, None) == -1
+    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, 0, None, None, None) == -1
     assert hip_lib.bh_candidate_step(None, None, None, None, None, None, None, None, None, None, None) == -1
 
 
@@ -209,8 +209,8 @@ def test_no_compatibility_layers_in_the_product():
 
 
 def test_forward_rows_and_mt_group_bounds_host_arithmetic(hip_lib):
-    """Persistent-grid sizing of kernel A (bh_gm_fwd_rows / bh_gm_set_rows_cap) and the 128-tensor launch groups of the
-    multi-tensor kernels (bh_mt_group_bounds): pure host arithmetic."""
+    """Persistent-grid sizing of kernel A (bh_gm_fwd_rows with its rows-cap ARGUMENT -- the library keeps no tuning state) and
+    the 128-tensor launch groups of the multi-tensor kernels (bh_mt_group_bounds): pure host arithmetic."""
     from ctypes import byref, c_int32, c_int64
 
     from breaching_amd import _lib
@@ -224,30 +224,30 @@ def test_forward_rows_and_mt_group_bounds_host_arithmetic(hip_lib):
         assert hip_lib.bh_gm_build_table(len(numel), arr, chunks, n_chunks.value, offs) == 0
         return chunks, n_chunks.value
 
-    try:
-        # ResNet-18 sized: 2893 chunks in one launch group -> ceil(2893 / ceil(2893 / cap)) workgroups
-        numel = [4096] * 2893
-        chunks, n = table(numel)
-        bounds = (c_int32 * (hip_lib.bh_gm_num_groups(len(numel)) + 1))()
-        assert hip_lib.bh_gm_group_bounds(len(numel), chunks, n, bounds) == 0
-        groups = hip_lib.bh_gm_num_groups(len(numel))
-        assert groups == 7 and bounds[groups] == n
-        for cap in (512, 2048, 100, 1):
-            assert hip_lib.bh_gm_set_rows_cap(cap) == 0
-            rows = hip_lib.bh_gm_fwd_rows(len(numel), bounds)
-            want = 0
-            for g in range(groups):
-                c = bounds[g + 1] - bounds[g]
-                rounds = -(-c // cap)
-                want += -(-c // rounds)
-                assert -(-c // rounds) <= cap
-            assert rows == want
-        assert hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS) == 0
-        one = (c_int32 * 2)(0, 2893)  # a single launch group holding all chunks (62 tensors in reality)
-        assert hip_lib.bh_gm_fwd_rows(62, one) == 483  # 6 rounds of 483 workgroups: every workgroup streams 5 or 6 chunks
-        assert hip_lib.bh_gm_fwd_rows(0, one) == -1 and hip_lib.bh_gm_fwd_rows(62, None) == -1
-    finally:
-        hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
+    # ResNet-18 sized: 2893 chunks in one launch group -> ceil(2893 / ceil(2893 / cap)) workgroups
+    numel = [4096] * 2893
+    chunks, n = table(numel)
+    bounds = (c_int32 * (hip_lib.bh_gm_num_groups(len(numel)) + 1))()
+    assert hip_lib.bh_gm_group_bounds(len(numel), chunks, n, bounds) == 0
+    groups = hip_lib.bh_gm_num_groups(len(numel))
+    assert groups == 7 and bounds[groups] == n
+    for cap in (512, 2048, 100, 1):
+        rows = hip_lib.bh_gm_fwd_rows(len(numel), bounds, cap)
+        want = 0
+        for g in range(groups):
+            c = bounds[g + 1] - bounds[g]
+            rounds = -(-c // cap)
+            want += -(-c // rounds)
+            assert -(-c // rounds) <= cap
+        assert rows == want
+    assert hip_lib.bh_gm_fwd_rows(len(numel), bounds, 0) == hip_lib.bh_gm_fwd_rows(len(numel), bounds, _lib.BH_GM_DEFAULT_ROWS)
+    one = (c_int32 * 2)(0, 2893)  # a single launch group holding all chunks (62 tensors in reality)
+    assert hip_lib.bh_gm_fwd_rows(62, one, 0) == 483  # 6 rounds of 483 workgroups: every workgroup streams 5 or 6 chunks
+    assert hip_lib.bh_gm_fwd_rows(0, one, 0) == -1 and hip_lib.bh_gm_fwd_rows(62, None, 0) == -1
+    assert hip_lib.bh_gm_fwd_rows(62, one, -1) == -1 and hip_lib.bh_gm_fwd_rows(62, one, _lib.BH_GM_MAX_ROWS + 1) == -1
+    # the tuning knobs of round 3 are gone from the ABI: nothing in the library is mutable from outside a launch
+    for gone in ("bh_gm_set_rows_cap", "bh_bn_set_grid_cap", "bh_bn_set_finalize_block", "bh_bn_set_load_depth"):
+        assert not hasattr(hip_lib, gone), gone
     # multi-tensor launch groups: 300 small tensors -> 3 groups of 128 / 128 / 44 tensors, one chunk each
     numel = [10 + i for i in range(300)]
     chunks, n = table(numel)
@@ -289,8 +289,12 @@ def test_model_kernels_reject_bad_arguments_before_launching(hip_lib):
     assert hip_lib.bh_bn_eval_fwd(ok, None, None, ok, ok, None, None, 1, 4, 16, None) == -1          # y missing
     assert hip_lib.bh_bn_eval_fwd(ok, None, None, ok, ok, ok, None, 0, 4, 16, None) == -1            # B = 0
     assert hip_lib.bh_bn_eval_fwd(ok + 4, None, None, ok, ok, ok, None, 1, 4, 16, None) == -1        # misaligned for 16-byte access
-    assert hip_lib.bh_bn_eval_bwd(None, ok, None, ok, ok, ok, ok, ok, None, 1, 4, 16, None) == -1    # gy missing
-    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, 8, 4, 112 * 112, None) == -1  # S > 1 needs a workspace
+    assert hip_lib.bh_bn_eval_bwd(None, ok, None, ok, ok, ok, ok, ok, None, None, None, 1, 4, 16, None) == -1    # gy missing
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, None, None, 8, 4, 112 * 112, None) == -1  # S > 1 needs a workspace
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, ok + 4, None, 1, 4, 16, None) == -1   # tap pairs 8-byte aligned
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, None, ok, ok, None, ok, None, 1, 4, 16, None) == -1     # tap needs gx
+    assert hip_lib.bh_bn_sums(1, None, None, ok, ok, 1, ok, 0, 3, None) == -1                                  # load depth 4 / 8 / 0
+    assert hip_lib.bh_bn_finalize(1, ok, ok, ok, ok, ok, ok, ok, ok, 128, None) == -1                          # block 256 / 512 / 1024 / 0
     assert hip_lib.bh_bn_eval_bwd_bwd(None, None, None, None, ok, None, ok, ok, ok, ok, None, None, 1, 4, 16, None) == -1
     assert hip_lib.bh_ln_fwd(None, None, None, ok, ok, ok, 4, 8, 1e-5, None) == -1
     assert hip_lib.bh_ln_fwd(ok, None, None, ok, None, ok, 4, 8, 1e-5, None) == -1                   # mean missing

@@ -357,20 +357,18 @@ def test_gm_forward_rows_cap_only_changes_summation_order(hip_lib):
     data = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
     rec = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
     results = {}
-    try:
-        for cap in (2048, 512, 64, 3):
-            assert hip_lib.bh_gm_set_rows_cap(cap) == 0
-            plan = GradientMatchPlan(data)
-            assert plan.n_rows <= 2 * cap
-            for kind in (0, 4, 6):
-                w = torch.linspace(1.0, 0.1, len(shapes), device=_dev()) if kind == 6 else None
-                first = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w).cpu()
-                again = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w).cpu()
-                assert torch.equal(first[:6], again[:6])  # fixed combine order: bitwise reproducible for a fixed geometry
-                results[(cap, kind)] = first[:6].double().numpy()
-    finally:
-        hip_lib.bh_gm_set_rows_cap(_lib.BH_GM_DEFAULT_ROWS)
-    assert hip_lib.bh_gm_set_rows_cap(0) == -1 and hip_lib.bh_gm_set_rows_cap(4096) == -1
+    plans = {cap: GradientMatchPlan(data, rows_cap=cap) for cap in (2048, 512, 64, 3)}  # the cap is a plan field: plans with
+    for cap, plan in plans.items():                                                     # different caps coexist in one process
+        assert plan.n_rows <= 2 * cap
+        for kind in (0, 4, 6):
+            w = torch.linspace(1.0, 0.1, len(shapes), device=_dev()) if kind == 6 else None
+            first = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w).cpu()
+            again = plan.forward(kind, rec, 1.5, 0.1, 1e-7, w).cpu()
+            assert torch.equal(first[:6], again[:6])  # fixed combine order: bitwise reproducible for a fixed geometry
+            results[(cap, kind)] = first[:6].double().numpy()
+    assert GradientMatchPlan(data).n_rows == plans[512].n_rows == GradientMatchPlan(data, rows_cap=_lib.BH_GM_DEFAULT_ROWS).n_rows
+    with pytest.raises(Exception):
+        GradientMatchPlan(data, rows_cap=4096)
     for kind in (0, 4, 6):
         for cap in (512, 64, 3):
             np.testing.assert_allclose(results[(cap, kind)], results[(2048, kind)], rtol=2e-6)
@@ -661,6 +659,146 @@ def test_deepinversion_statistics_come_from_the_batchnorm_forward_kernel(kernels
     want = sum(0.25 * (10 if i == 0 else 1) * kernels_ref.bnstat(a.cpu().numpy(), bn.running_mean.cpu().numpy(), bn.running_var.cpu().numpy())[0]
                for i, (a, bn) in enumerate(zip(acts, bns)))
     assert abs(v2 - want) <= 5e-6 * abs(want)
+
+
+def _bn_tap_model(dev):
+    torch.manual_seed(5)
+    model = torch.nn.Sequential(
+        torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.Tanh(),
+        torch.nn.Conv2d(8, 12, 3, stride=2, padding=1), torch.nn.BatchNorm2d(12), torch.nn.Tanh(),
+        torch.nn.Conv2d(12, 6, 3, stride=2, padding=0), torch.nn.BatchNorm2d(6)).to(dev).eval()
+    for bn in model:
+        if isinstance(bn, torch.nn.BatchNorm2d):
+            bn.running_mean.normal_(0, 0.3)
+            bn.running_var.uniform_(0.5, 1.5)
+    return model
+
+
+def test_deepinversion_backward_rides_in_the_batchnorm_backward_launch(hip_lib, monkeypatch):
+    """The prior's backward term gout * (A_c + B_c * x) of a BatchNorm INPUT is added by that layer's own backward launch
+    (bh_bn_eval_bwd with its tap arguments; the launch reads x anyway) instead of a read-modify-write launch per layer
+    (bh_bn_bwd_accumulate).  Checked on the attack's autograd shape -- first-order pass under create_graph, gradient-matching
+    style scalar of the parameter gradients, plus the prior, one gradient back to the input -- against (a) round 3's separate
+    launch (BREACH_HIP_BN_FUSED_TAP=0), (b) the prior as plain torch fp64 autograd on the CPU.  deepinversion.py:93-103 (math)."""
+    import copy
+
+    from breaching_amd.attacker import use_affine_eval_batchnorm
+    from breaching_amd.priors import HipDeepInversion
+
+    dev = _dev()
+    base = _bn_tap_model(dev)
+    x0 = torch.randn(4, 3, 112, 112, device=dev)
+    mixes = [torch.randn_like(p) for p in base.parameters()]
+
+    def attack_gradient(model, prior, x, cast=lambda t: t):
+        xq = x.detach().clone().requires_grad_(True)
+        out = model(xq)
+        value = prior(xq)
+        first = torch.autograd.grad((out ** 2).mean(), list(model.parameters()), create_graph=True)
+        scalar = sum((g * cast(m)).sum() for g, m in zip(first, mixes))
+        (g,) = torch.autograd.grad(scalar + 0.7 * value, xq)
+        return value.detach(), g
+
+    model = use_affine_eval_batchnorm(copy.deepcopy(base), "hip")
+    prior = HipDeepInversion(dict(device=dev, dtype=torch.float), scale=0.25, first_bn_multiplier=10)
+    prior.initialize([model])
+    attack_gradient(model, prior, x0)  # first evaluation builds the plan
+    v_fused, g_fused = attack_gradient(model, prior, x0)
+    assert all(h.in_producer and h.fed for h in prior.losses[0])  # no identity node, no sums pass, no launch of its own
+    monkeypatch.setenv("BREACH_HIP_BN_FUSED_TAP", "0")
+    v_sep, g_sep = attack_gradient(model, prior, x0)
+    assert not any(h.in_producer for h in prior.losses[0])
+    monkeypatch.delenv("BREACH_HIP_BN_FUSED_TAP")
+    assert float((v_fused - v_sep).abs()) <= 1e-6 * float(v_sep.abs())
+    _assert_grads([g_fused.cpu().numpy()], [g_sep.cpu().numpy().astype(np.float64)], rtol=2e-6)
+
+    # (b) the same quantity with the statistic written in torch ops, fp64, CPU, stock BatchNorm modules
+    ref = copy.deepcopy(base).double().cpu()
+
+    class TorchPrior:
+        def __init__(self):
+            self.acts = []
+            for m in ref:
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.register_forward_hook(lambda mod, inp, out: self.acts.append((inp[0], mod)))
+
+        def __call__(self, _):
+            total = 0
+            for i, (a, mod) in enumerate(self.acts):
+                mean = a.mean(dim=(0, 2, 3))
+                var = a.permute(1, 0, 2, 3).reshape(a.shape[1], -1).var(1, unbiased=False)
+                total = total + 0.25 * (10 if i == 0 else 1) * (torch.norm(mod.running_var - var, 2) + torch.norm(mod.running_mean - mean, 2))
+            self.acts.clear()
+            return total
+
+    mixes_dev = mixes
+    mixes = [m.double().cpu() for m in mixes_dev]
+    v_ref, g_ref = attack_gradient(ref, TorchPrior(), x0.double().cpu())
+    mixes = mixes_dev
+    assert abs(float(v_fused) - float(v_ref)) <= 5e-6 * abs(float(v_ref))
+    _assert_grads([g_fused.cpu().numpy()], [g_ref.numpy()], rtol=5e-5)
+
+
+def test_deepinversion_coefficients_are_bound_to_their_forward_pass(hip_lib):
+    """A backward through a RETAINED graph applies the (A_c, B_c) of the pass that built it, not those of a later pass of
+    the same model (trials in flight share the modules; round 3 kept one record per model)."""
+    from breaching_amd.attacker import use_affine_eval_batchnorm
+    from breaching_amd.priors import HipDeepInversion
+
+    dev = _dev()
+    for mode in ("1", "0"):  # fused into kernel E's backward / separate tap launch
+        os.environ["BREACH_HIP_BN_FUSED_TAP"] = mode
+        try:
+            model = use_affine_eval_batchnorm(_bn_tap_model(dev), "hip")
+            prior = HipDeepInversion(dict(device=dev, dtype=torch.float), scale=0.25, first_bn_multiplier=10)
+            prior.initialize([model])
+            xa = torch.randn(2, 3, 64, 64, device=dev, requires_grad=True)
+            xb = (3.0 * torch.randn(2, 3, 64, 64, device=dev) + 1.0).requires_grad_(True)
+            model(xa), prior(xa)  # plan
+            model(xa)
+            va = prior(xa)
+            (want,) = torch.autograd.grad(va, xa, retain_graph=True)
+            model(xb)
+            vb = prior(xb)  # a later pass overwrites nothing the first one needs
+            prior.release_graph()
+            (again,) = torch.autograd.grad(va, xa)
+            (gb,) = torch.autograd.grad(vb, xb)
+            assert torch.equal(want, again)
+            assert not torch.allclose(gb, want)
+        finally:
+            os.environ.pop("BREACH_HIP_BN_FUSED_TAP", None)
+
+
+def test_bn_eval_bwd_tap_arguments_against_numpy(hip_lib):
+    """bh_bn_eval_bwd with (tap_coef, tap_gout): gx = gy * s_c + gout * (A_c + B_c * x); gw / gb unchanged.  Wide, slab-split,
+    narrow and scalar (HW % 4 != 0) geometries."""
+    from breaching_amd import _lib
+
+    rng = np.random.default_rng(11)
+    for shape in [(1, 64, 56, 56), (8, 5, 112, 112), (2, 12, 7, 7), (3, 5, 9, 11)]:
+        B, C, HW = shape[0], shape[1], shape[2] * shape[3]
+        host = {k: rng.standard_normal(shape).astype(np.float32) for k in ("gy", "x")}
+        w, inv, mi = (rng.uniform(0.5, 1.5, C).astype(np.float32) for _ in range(3))
+        coef = rng.standard_normal((C, 2)).astype(np.float32)
+        gout = np.float32(0.37)
+        t = {k: torch.tensor(v, device=_dev()) for k, v in dict(host, w=w, inv=inv, mi=mi, coef=coef.reshape(-1)).items()}
+        g = torch.tensor([gout], device=_dev())
+        out = {}
+        for tap in (False, True):
+            gx, gw, gb = torch.empty_like(t["x"]), torch.empty(C, device=_dev()), torch.empty(C, device=_dev())
+            S = hip_lib.bh_bn_eval_slabs(B, C, HW)
+            ws = torch.empty(2 * C * S, dtype=torch.float64, device=_dev())
+            _lib.check(hip_lib.bh_bn_eval_bwd(_lib.ptr(t["gy"]), _lib.ptr(t["x"]), _lib.ptr(t["w"]), _lib.ptr(t["inv"]), _lib.ptr(t["mi"]),
+                                              _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), _lib.ptr(t["coef"] if tap else None),
+                                              _lib.ptr(g if tap else None), B, C, HW, _lib.current_stream_handle(_dev())), "bwd")
+            out[tap] = [v.cpu().numpy().astype(np.float64) for v in (gx, gw, gb)]
+        s = (w.astype(np.float64) * inv)[None, :, None, None]
+        plain = host["gy"].astype(np.float64) * s
+        tapped = plain + float(gout) * (coef[:, 0].astype(np.float64)[None, :, None, None] + coef[:, 1].astype(np.float64)[None, :, None, None] * host["x"])
+        np.testing.assert_allclose(out[False][0], plain, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(out[True][0], tapped, rtol=2e-6, atol=5e-7)
+        np.testing.assert_array_equal(out[True][1], out[False][1])
+        np.testing.assert_array_equal(out[True][2], out[False][2])
 
 
 @pytest.mark.parametrize("shape,affine", [((1, 32, 768), True), ((2, 8, 64), True), ((7, 130), True), ((3, 5, 37), False), ((300, 96), True)])

@@ -430,20 +430,28 @@ def test_implementation_switches(monkeypatch):
     eval-mode BatchNorm and LayerNorm layers of the model copy run."""
     from breaching_amd import attacker, get_attack_config
 
-    for name in ("BREACH_HIP_GRAPH", "BREACH_HIP_TRIALS_IN_FLIGHT", "BREACH_HIP_FAST_BN", "BREACH_HIP_FAST_LN"):
+    for name in ("BREACH_HIP_GRAPH", "BREACH_HIP_GRAPH_STRICT", "BREACH_HIP_TRIALS_IN_FLIGHT", "BREACH_HIP_FAST_BN", "BREACH_HIP_FAST_LN"):
         monkeypatch.delenv(name, raising=False)
     cfg = get_attack_config("invertinggradients")
-    assert attacker.graph_replay_policy(cfg) == "on" and attacker.graph_replay_enabled(cfg)
+    assert attacker.graph_replay_policy(cfg) == "auto" and attacker.graph_replay_enabled(cfg)  # never a crash by default
     assert attacker.trials_in_flight(cfg) == attacker.DEFAULT_TRIALS_IN_FLIGHT == 4
     assert attacker.fast_eval_bn_mode(cfg) == "hip" and attacker.fast_layer_norm_enabled(cfg)
-    cfg = get_attack_config("invertinggradients", ["impl.hip_graph=auto", "impl.trials_in_flight=9", "impl.fast_eval_bn=addcmul",
+    cfg = get_attack_config("invertinggradients", ["impl.hip_graph=required", "impl.trials_in_flight=9", "impl.fast_eval_bn=addcmul",
                                                    "impl.fast_layer_norm=False"])
-    assert attacker.graph_replay_policy(cfg) == "auto" and attacker.graph_replay_enabled(cfg)
+    assert attacker.graph_replay_policy(cfg) == "required" and attacker.graph_replay_enabled(cfg)
     assert attacker.trials_in_flight(cfg) == attacker.MAX_TRIALS_IN_FLIGHT  # more than four concurrent replays run slower
     assert attacker.fast_eval_bn_mode(cfg) == "addcmul" and not attacker.fast_layer_norm_enabled(cfg)
     cfg = get_attack_config("invertinggradients", ["impl.hip_graph=False", "impl.fast_eval_bn=False", "impl.trials_in_flight=2"])
     assert attacker.graph_replay_policy(cfg) == "off" and not attacker.graph_replay_enabled(cfg)
     assert attacker.fast_eval_bn_mode(cfg) is None and not attacker.fast_eval_bn_enabled(cfg) and attacker.trials_in_flight(cfg) == 2
+    monkeypatch.setenv("BREACH_HIP_GRAPH", "required")
+    assert attacker.graph_replay_policy(cfg) == "required"
+    monkeypatch.setenv("BREACH_HIP_GRAPH", "auto")
+    monkeypatch.setenv("BREACH_HIP_GRAPH_STRICT", "1")
+    assert attacker.graph_replay_policy(cfg) == "required"
+    monkeypatch.delenv("BREACH_HIP_GRAPH")
+    assert attacker.graph_replay_policy(cfg) == "off"  # cfg says hip_graph=False: strictness never switches capture on
+    monkeypatch.delenv("BREACH_HIP_GRAPH_STRICT")
     monkeypatch.setenv("BREACH_HIP_GRAPH", "auto")
     monkeypatch.setenv("BREACH_HIP_FAST_BN", "hip")
     monkeypatch.setenv("BREACH_HIP_FAST_LN", "1")
@@ -470,3 +478,19 @@ def test_model_copy_modules_are_swapped_in_place():
     x = torch.randn(2, 3, 8, 8)
     torch.testing.assert_close(model.eval()(x), reference.eval()(x), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(model.train()(x), reference.train()(x), rtol=1e-5, atol=1e-6)
+    # torch.func transforms: the custom autograd Functions have no functorch rules, so the swapped modules must notice a
+    # transform (and route to the torch formulation); vmap(grad) over the swapped model works and agrees with the stock one
+    from breaching_amd.attacker import _under_functorch
+
+    seen = []
+
+    def probe(v):
+        seen.append(_under_functorch(v))
+        return (v * v).sum()
+
+    assert not _under_functorch(x)
+    torch.func.vmap(torch.func.grad(probe))(x)
+    assert seen == [True]
+    model.eval(), reference.eval()
+    per_sample = lambda m: torch.func.vmap(torch.func.grad(lambda v: (m(v[None]) ** 2).sum()))(x)  # noqa: E731
+    torch.testing.assert_close(per_sample(model), per_sample(reference), rtol=1e-3, atol=1e-4)

@@ -49,12 +49,16 @@ def test_pool_runs_jobs_selects_and_survives_errors():
     pool = TrialWorkerPool([None, None, None], _runner_factory, (num_trials,))
     try:
         assert pool.backend == "gloo" and pool.world == 3 and workers.active_pool() is pool
+        # start-up has its own, longer limit than the collectives (cold `import torch` in every worker); both are reported
+        assert pool.start_timeout == workers.DEFAULT_START_TIMEOUT > pool.collective_timeout == workers.DEFAULT_COLLECTIVE_TIMEOUT
+        assert pool.describe()["pool_start_s"] > 0
         for scores in ([3.0, 0.25, 7.0, float("nan"), 0.5], [9.0, 8.0, 7.0, 6.0, 0.125]):
             pool.submit([dict(scores=scores)] * 2)
             shard = trials.TrialShard.current(num_trials)
             assert (shard.rank, shard.world) == (0, 3) and list(shard.local_trials()) == [0, 3]
             solutions = {t: torch.full((2, 3), float(t)) for t in shard.local_trials()}
             stats = {f"Trial_{t}_Val": [float(t)] * 3 for t in shard.local_trials()}
+            assert pool.describe()["job_ship_s"] >= 0
             pool.expect("trials_done")
             pool.broadcast(("go",))
             value, solution = shard.select(solutions, {t: scores[t] for t in shard.local_trials()}, stats, torch.device("cpu"))
@@ -131,3 +135,17 @@ def test_requested_devices_parsing(monkeypatch):
     monkeypatch.setenv("BREACH_HIP_TRIAL_DEVICES", "1,0")
     with pytest.raises(ValueError, match="must start with"):
         requested_devices(cfg, dev)
+
+
+def test_each_rank_gets_its_own_miopen_user_db(monkeypatch, tmp_path):
+    """Eight first processes on a fresh box must not share one MIOpen find-db file (lock contention, solver timings taken
+    against each other): every rank points MIOPEN_USER_DB_PATH at its own directory unless the user already chose one."""
+    from breaching_amd import workers
+
+    monkeypatch.setenv("HOME", str(tmp_path))
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    first = workers.isolate_miopen_user_db(3)
+    assert first.endswith("breach_hip_rank3") and first.startswith(str(tmp_path)) and __import__("os").path.isdir(first)
+    assert workers.isolate_miopen_user_db(5) == first  # already set in this process (by the call above): left alone
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    assert workers.isolate_miopen_user_db(1) == "/somewhere/else"
