@@ -17,8 +17,13 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     over the average launch duration measured with HIP events (hipExtLaunchKernelGGL start/stop = the dispatch's own
     timestamps) on the launch stream; `stage_*` adds the one-workgroup finalize launch; `timed_region_span_*` is the device
     wall-clock span of the forward launches inside the timed graph-replay region.
-  * cpu_baseline: oracle/restate.py (CPU restatement of the reference, pinned to it by tests/test_oracle_pinning.py) on
-    the host cores, same workload, a bounded number of iterations, rank 0 at N=1 only.
+    `roofline.hbm_resident`: the same kernels timed in the same run on a synthetic list of BERT-base's 201 gradient tensors
+    (86.07 M elements, 688.6 MB per forward launch -- 2.7x the 256 MiB Infinity Cache, so this is an HBM figure, which the
+    ResNet-18 list's is not).
+  * cpu_baseline: the UNMODIFIED reference through oracle/ref_shim.py when a reference checkout is importable
+    (`kind: "reference"`; /root/reference in the build container, BREACHING_REFERENCE elsewhere), else oracle/restate.py (CPU
+    restatement pinned to the reference by tests/test_oracle_pinning.py; `kind: "port"`, with the committed port / reference
+    anchor ratio next to it) -- on the host cores, same workload, a bounded number of iterations, rank 0 at N=1 only.
 """
 
 import argparse
@@ -63,13 +68,78 @@ def pmc_traffic_bytes(kernel, sources=None):
     return int(total) if found == 2 else None
 
 
+def bert_base_gradient_shapes():
+    """The 201 gradient tensors a TAG attack on BERT-base (MLM head, vocabulary 30 522) matches: every parameter but the
+    word-embedding matrix (base_attack.py:94 pops it).  86 073 402 elements (SURVEY.md section 8 size table)."""
+    H, I, V = 768, 3072, 30522
+    shapes = [(512, H), (2, H), (H,), (H,)]  # position / token-type embeddings, embedding LayerNorm
+    for _ in range(12):
+        shapes += [(H, H), (H,)] * 4 + [(H,), (H,)] + [(I, H), (I,), (H, I), (H,)] + [(H,), (H,)]
+    shapes += [(H, H), (H,), (H,), (H,), (V,)]  # MLM transform, its LayerNorm, decoder bias (decoder weight is tied)
+    return shapes
+
+
+def hbm_resident_leg(device, reps=30):
+    """Kernel A forward / finalize / backward with hipExtLaunchKernelGGL events on a list that cannot sit in the Infinity Cache."""
+    import torch
+
+    from breaching_amd import _lib
+    from breaching_amd.gm import GradientMatchPlan
+
+    shapes = bert_base_gradient_shapes()
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    data = [torch.randn(s, generator=gen).to(device) for s in shapes]
+    rec = [torch.randn(s, generator=gen).to(device) for s in shapes]
+    plan = GradientMatchPlan(data)
+    n = plan.total_elements
+    out = dict(list=f"BERT-base gradient list without the word embedding: {len(shapes)} tensors, {n} elements "
+                    f"({2 * n * 4 / 1e6:.1f} MB per forward launch)", elements=n, measured="hipExtLaunchKernelGGL start/stop events, "
+               f"{reps} back-to-back forward + finalize + backward triples on the current stream, the 5 slowest dropped")
+    for kind_name in ("cosine-similarity", "tag-euclidean"):
+        kind = _lib.GM_KINDS[kind_name]
+        weights = torch.linspace(1, 0.1, len(shapes), device=device) if kind_name == "tag-euclidean" else None
+        for _ in range(3):
+            plan.backward(kind, rec, plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights), None, weights)
+        plan.enable_timing()
+        for _ in range(reps):
+            plan.backward(kind, rec, plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights), None, weights)
+        torch.cuda.synchronize(device)
+        t = plan.drain_timers()
+        f, e, b = (sum(sorted(t[k])[:-5]) / (len(t[k]) - 5) for k in ("fwd", "fin", "bwd"))
+        out[kind_name] = dict(fwd_us=round(f, 2), finalize_us=round(e, 2), bwd_us=round(b, 2),
+                              fwd_GBs=round(2 * n * 4 / f / 1e3, 1), frac=round(2 * n * 4 / f / 1e3 / HBM_PEAK_GBS, 4),
+                              stage_frac=round(2 * n * 4 / (f + e) / 1e3 / HBM_PEAK_GBS, 4),
+                              bwd_GBs=round(3 * n * 4 / b / 1e3, 1), bwd_frac=round(3 * n * 4 / b / 1e3 / HBM_PEAK_GBS, 4))
+    plan.timers = None
+    return out
+
+
+def cpu_anchor_ratio():
+    """port / reference iterations-per-second ratio from the committed anchor measurements (scripts/cpu_baseline_anchor.py:
+    the unmodified reference and oracle/restate.py timed on the same threads in the build container), newest file."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_baseline_anchor.json")))
+    if not paths:
+        return None
+    try:
+        with open(paths[-1]) as f:
+            rec = json.load(f)
+        return dict(port_over_reference=rec.get("port_over_reference"), file=os.path.basename(paths[-1]), threads=rec.get("threads"))
+    except Exception:
+        return None
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--cpu-baseline-iters", type=int, default=80,
-                   help="timed CPU iterations of the oracle, ~10 s of host work (0 disables)")
+                   help="timed CPU iterations of the reference (or its port), ~10 s of host work (0 disables)")
+    p.add_argument("--cpu-threads", type=int, default=0,
+                   help="threads of the CPU baseline (0 = min(os.cpu_count(), 32): the measured optimum, profiles/r4_cpu_thread_sweep.json)")
+    p.add_argument("--no-hbm-resident", action="store_true", help="skip the BERT-base sized kernel-A timing (roofline.hbm_resident)")
     p.add_argument("--model", default="resnet18")
     p.add_argument("--no-kernel-timing", action="store_true")
     p.add_argument("--no-span-timing", action="store_true",
@@ -112,6 +182,13 @@ def main():
         raise SystemExit(subprocess.run(cmd).returncode)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if world > 1:
+        # every rank is a first process on a fresh box: its own MIOpen user find-db, so that eight solver searches do not queue
+        # on one sqlite lock (they all finish inside the untimed warm-up iterations; the barrier in front of the timed region
+        # waits for the slowest)
+        from breaching_amd.workers import isolate_miopen_user_db
+
+        isolate_miopen_user_db(rank)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     oversubscribed = world > torch.cuda.device_count()
@@ -140,7 +217,8 @@ def main():
     # ---- workload --------------------------------------------------------------------------------------------------
     torch.manual_seed(0)
     case = build_case(args.model, "ImageNet", 1, device=device, gradient_device=device)
-    cfg = breaching_amd.get_attack_config("invertinggradients", [f"restarts.num_trials={world}"])
+    # hip_graph=required: a failed capture must fail the bench, not time eager launches under the graph's name
+    cfg = breaching_amd.get_attack_config("invertinggradients", [f"restarts.num_trials={world}", "impl.hip_graph=" + ("False" if args.no_graph else "required")])
     setup = dict(device=device, dtype=torch.float)
     attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
     rec_models, labels, stats = attacker.prepare_attack(case.server_payload, case.shared_data)
@@ -207,8 +285,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     span_us, span_launches = plan.forward_span_us() if plan is not None else (None, 0)
+    per_rank_ms = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)  # every rank's own wall time of the same K steps: the skew shows a straggler GPU / rank
+        per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 4) for v in everyone]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     mode = "hipGraph replay" if run.graph is not None else "eager launches"
@@ -281,6 +364,12 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 4), traffic=pmc_traffic_bytes("gm_fwd_kernel"),
                         avg_launch_us=round(span_us, 2), launches=span_launches, algorithmic_bytes=fwd_bytes,
                         measured="device wall clock (first workgroup in -> last workgroup out) of every launch in the timed region")
+    if roofline is not None and rank == 0 and world == 1 and not args.no_hbm_resident and not args.no_kernel_timing:
+        try:
+            with torch.cuda.stream(first_stream):
+                roofline["hbm_resident"] = hbm_resident_leg(device)
+        except Exception as exc:  # e.g. out of memory next to another tenant: reported, never fatal for the headline value
+            roofline["hbm_resident"] = dict(error=repr(exc))
     if "bwd" in kernels:
         kernels["bwd"]["traffic"] = pmc_traffic_bytes("gm_bwd_kernel")
         kernels["bwd"]["frac_of_hbm_peak"] = round(kernels["bwd"]["achieved_GBs"] / HBM_PEAK_GBS, 4)
@@ -318,22 +407,52 @@ def main():
     # ---- CPU baseline (rank 0, N == 1 only) ---------------------------------------------------------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
-        from oracle import restate
-
         host_cores = os.cpu_count() or 1
-        threads = min(host_cores, 32)  # torch's CPU convolutions stop scaling well before 32 threads on this workload
+        # torch's CPU convolutions stop scaling well before 32 threads on this B = 1 workload and lose beyond it (measured on the
+        # 256-logical-core host of the GPU box: profiles/r4_cpu_thread_sweep.json); --cpu-threads overrides
+        threads = args.cpu_threads if args.cpu_threads > 0 else min(host_cores, 32)
         torch.set_num_threads(threads)
         cpu_case = build_case(args.model, "ImageNet", 1, device="cpu")
-        cpu_cfg = breaching_amd.get_attack_config("invertinggradients")
         x0_cpu = initial_candidate(cpu_case.data_cfg, 1)
-        restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
-                           initial_data=x0_cpu, max_iterations=2)  # warm-up (allocator, oneDNN primitives)
-        timing = []
-        restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
-                           initial_data=x0_cpu, max_iterations=args.cpu_baseline_iters, timing=timing)
-        cpu_baseline = dict(value=round(args.cpu_baseline_iters / timing[0], 3), unit="attack iterations/s", cores=threads,
-                            host_cpu_count=host_cores, kind="port", sample=f"{args.cpu_baseline_iters} iterations of the same ResNet-18/224 invertinggradients "
-                            f"workload through oracle/restate.py (torch {torch.__version__} CPU), after 2 warm-up iterations")
+        iters = args.cpu_baseline_iters
+        reference_root = os.environ.get("BREACHING_REFERENCE", "/root/reference")
+        kind, seconds, note = "port", None, None
+        if os.path.isdir(os.path.join(reference_root, "breaching")):
+            try:  # the unmodified reference, exactly as oracle/make_golden.py runs it
+                from oracle.make_golden import _cfg as reference_cfg
+                from oracle.make_golden import _run_reference_attack
+
+                def timed_reference(its):
+                    tc = time.perf_counter()
+                    _run_reference_attack(reference_cfg("invertinggradients", [f"optim.max_iterations={its}", "optim.callback=100000"]), cpu_case, x0_cpu)
+                    return time.perf_counter() - tc
+
+                timed_reference(2)  # warm-up: allocator, oneDNN primitives, TorchScript
+                # a reconstruct() call includes the model rebuild and the final rescoring: a 2-iteration call is subtracted to
+                # isolate the loop (same method as scripts/cpu_baseline_anchor.py)
+                short = timed_reference(2)
+                seconds, kind = timed_reference(2 + iters) - short, "reference"
+                note = (f"{iters} loop iterations of the same ResNet-18/224 invertinggradients workload through the UNMODIFIED reference "
+                        f"({reference_root} via oracle/ref_shim.py; torch {torch.__version__} CPU): a (2 + {iters})-iteration reconstruct() minus "
+                        "a 2-iteration one, after a warm-up call")
+            except Exception as exc:
+                note = f"reference checkout found but not runnable ({exc!r}); "
+        if seconds is None:
+            from oracle import restate
+
+            cpu_cfg = breaching_amd.get_attack_config("invertinggradients")
+            restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
+                               initial_data=x0_cpu, max_iterations=2)  # warm-up (allocator, oneDNN primitives)
+            timing = []
+            restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
+                               initial_data=x0_cpu, max_iterations=iters, timing=timing)
+            seconds = timing[0]
+            note = (note or "") + (f"{iters} iterations of the same ResNet-18/224 invertinggradients workload through oracle/restate.py (torch "
+                                   f"{torch.__version__} CPU; no reference checkout on this box), after 2 warm-up iterations")
+        cpu_baseline = dict(value=round(iters / seconds, 3), unit="attack iterations/s", cores=threads, host_cpu_count=host_cores,
+                            kind=kind, sample=note)
+        if kind == "port":
+            cpu_baseline["anchor"] = cpu_anchor_ratio()  # how the port relates to the unmodified reference on equal threads
 
     if rank == 0:
         line = {
@@ -350,7 +469,9 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.model} (1000 classes, random init) 1x3x224x224, attack=invertinggradients "
-                                   "(cosine + TV 0.2, hard-sign Adam, boxed), one trial per GPU",
+                                   "(cosine + TV 0.2, hard-sign Adam, boxed), " +
+                                   ("one trial per GPU" if args.trials_per_gpu == 1 else
+                                    f"{args.trials_per_gpu} independent trials in flight per GPU (separate streams)"),
                        "gradient_list_elements": n_elements, "trials": world * args.trials_per_gpu,
                        "trials_in_flight_per_gpu": args.trials_per_gpu, "parallelism": f"trial-parallel x{world}"},
             "roofline": roofline,
@@ -360,6 +481,8 @@ def main():
             "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
             "graph_capture_error": graph_failed,
             "final_objective": state["total"],
+            "per_rank_ms_per_step": per_rank_ms,
+            "rank_skew": None if not per_rank_ms else round(max(per_rank_ms) / min(per_rank_ms), 4),
             "select_ms": select_ms,
             "score_ms": score_ms,
             "rccl_dry_run": rccl_dry_run,

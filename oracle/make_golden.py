@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY -- generate tests/golden/*.npz by running the UNMODIFIED reference in the build container.
 
     python -m oracle.make_golden [--only configs|kernels|schedules|convnet|resnet18|seethrough|tag|variants|fedavg|labels|dlg|multiquery|pearlmutter]
-    python -m oracle.make_golden --only resnet18_long|seethrough_b8|tag_bert_base|resnet18_24k   (slow: run by name only)
+    python -m oracle.make_golden --only resnet18_long|seethrough_b8|tag_bert_base|resnet18_24k|seethrough_noise   (slow: run by name only)
 
 Needs /root/reference (through oracle/ref_shim.py); the outputs are committed so that the GPU box -- which has no
 reference checkout -- can pin oracle/restate.py, oracle/kernels_oracle.c and the HIP path against real reference
@@ -704,7 +704,7 @@ def _resnet18_full_worker(idx, out_path, threads=2, iters=FULL_ITERS, forced=FUL
             ks.append(j), xs.append(rec_x[j].numpy()), gs.append(rec_raw[j].numpy()), ss.append(rec_sign[j].numpy().astype(np.int8))
             sens_kept.append(float(np.min(sens))), agree_kept.append(min(agree)), wagree_kept.append(min(wagree))
         out.update(forced_k=np.asarray(ks, dtype=np.int64), forced_x=np.stack(xs).astype(np.float32),
-                   forced_grad=np.stack(gs).astype(np.float32), forced_sign=np.stack(ss),
+                   forced_grad_bf16=np.stack([_bf16_bits(torch.as_tensor(g)) for g in gs]), forced_sign=np.stack(ss),
                    forced_sensitivity=np.asarray(sens_kept), forced_twin_sign_agreement=np.asarray(agree_kept),
                    forced_twin_weighted_sign_agreement=np.asarray(wagree_kept))
     np.savez(out_path, **out)
@@ -750,6 +750,68 @@ def assemble_resnet18_24k():
     np.savez_compressed(os.path.join(GOLDEN, "attack_resnet18_24k.npz"), **main)
 
 
+def _bf16_bits(t):
+    """fp32 tensor -> the upper 16 bits of every element (bfloat16 by truncation) as uint16: |g| to 0.4 %, enough to weight a
+    sign comparison, at half the bytes."""
+    return (t.detach().contiguous().view(torch.int32).numpy().astype(np.int64) >> 16).astype(np.uint16)
+
+
+def _reference_step_direction(case, cfg, x):
+    """(loss, raw d total/dx, candidate.grad after the closure) of the UNMODIFIED reference evaluated at x: a `dryrun`
+    reconstruct from initial_data = x with the closure spied on from outside (optimization_based_attack.py:145-189)."""
+    breaching = import_reference()
+    attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+    inner_compute = attacker._compute_objective
+    got = {}
+
+    def wrapped(candidate, labels, rec_model, optimizer, shared_data, iteration):
+        closure = inner_compute(candidate, labels, rec_model, optimizer, shared_data, iteration)
+        candidate.register_hook(lambda grad: got.__setitem__("raw", grad.detach().clone()))
+
+        def spy():
+            value = closure()
+            got["sign"] = candidate.grad.detach().clone()
+            return value
+
+        return spy
+
+    attacker._compute_objective = wrapped
+    torch.manual_seed(7)
+    shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+    _, stats = attacker.reconstruct(case.server_payload, shared, {}, initial_data=x, dryrun=True)
+    return stats["Trial_0_Val"][0], got["raw"], got["sign"]
+
+
+def golden_resnet18_long_signs():
+    """Step direction of the reference at the teacher-forcing iterates of attack_resnet18_long.npz (1000-iteration run): the
+    quantity hard-sign Adam consumes is sign(d total/dx) (optimization_based_attack.py:165,181-182), so a loss that agrees at
+    x_k is not enough.  For every stored x_k: the unmodified reference's sign map and raw gradient at x_k, and the
+    reference's OWN reproducibility of that map -- its agreement with the map at x_k moved by <= 16 ulp (3 draws; plain
+    pixel fraction and |g|-weighted) -- which is the yardstick a second implementation is held to."""
+    from breaching_amd.cases import build_case
+
+    torch.set_num_threads(2)
+    gold = np.load(os.path.join(GOLDEN, "attack_resnet18_long.npz"))
+    case = build_case("resnet18", "ImageNet", 1)
+    cfg = _cfg("invertinggradients", [f"optim.max_iterations={int(gold['iterations'])}"])
+    gen = torch.Generator().manual_seed(99)
+    out = dict(forced_k=gold["forced_k"])
+    signs, grads, agree, wagree, losses = [], [], [], [], []
+    for k, x in zip(gold["forced_k"], gold["forced_x"]):
+        x = torch.as_tensor(x)
+        loss, raw, sign = _reference_step_direction(case, cfg, x)
+        a, w = [], []
+        for _ in range(3):
+            _, raw2, sign2 = _reference_step_direction(case, cfg, _ulp_perturb(x, 16, gen))
+            same = (sign2 == sign).double()
+            a.append(float(same.mean())), w.append(float((same * raw.abs().double()).sum() / raw.abs().double().sum()))
+        print(f"  k={int(k)}: loss {loss:.6f} (history {float(gold['history'][k]):.6f}); twin sign agreement {a}, weighted {w}", flush=True)
+        signs.append(sign.numpy().astype(np.int8)), grads.append(_bf16_bits(raw)), agree.append(min(a)), wagree.append(min(w)), losses.append(loss)
+    out.update(forced_sign=np.stack(signs), forced_grad_bf16=np.stack(grads), forced_twin_sign_agreement=np.asarray(agree),
+               forced_twin_weighted_sign_agreement=np.asarray(wagree), forced_loss=np.asarray(losses))
+    np.savez_compressed(os.path.join(GOLDEN, "attack_resnet18_long_signs.npz"), **out)
+
+
 def golden_seethrough():
     from breaching_amd.cases import build_case, initial_candidate
 
@@ -767,6 +829,38 @@ def golden_seethrough():
     rec, stats = _run_reference_attack(cfg, case, x0, seed=11)
     out.update({f"noise_{k}": v for k, v in _attack_record(cfg, case, x0, rec, stats, crop=32).items()})
     np.savez_compressed(os.path.join(GOLDEN, "attack_seethrough.npz"), **out)
+
+
+NOISE_SEEDS = (11, 12, 13, 14, 15)
+NOISE_ITERS = 8
+
+
+def golden_seethrough_noise():
+    """The reference's own run-to-run envelope under Langevin noise: see-through-gradients on ResNet-50, 2 images, the shipped
+    noise 0.01, from ONE starting point with five different noise streams (torch.manual_seed before `reconstruct`; the CPU
+    run draws one noise tensor per iteration, optimization_based_attack.py:167-170).  A second implementation that draws
+    its noise on the device (another generator, hence another stream) can only be held to this envelope, not to one of its
+    members.  8 iterations with a 2-iteration warm-up."""
+    from breaching_amd.cases import build_case, initial_candidate, psnr
+
+    torch.set_num_threads(2)
+    case = build_case("resnet50", "ImageNet", 2, provide_buffers=True)
+    x0 = initial_candidate(case.data_cfg, 2)
+    cfg = _cfg("seethroughgradients", [f"optim.max_iterations={NOISE_ITERS}", "optim.warmup=2", "optim.callback=4"])
+    assert cfg.optim.langevin_noise == 0.01
+    hists, psnrs, opts, means, stds = [], [], [], [], []
+    for seed in NOISE_SEEDS:
+        rec, stats = _run_reference_attack(cfg, case, x0, seed=seed)
+        data = rec["data"].detach()
+        hists.append(np.asarray(stats["Trial_0_Val"], dtype=np.float64))
+        psnrs.append(psnr(data, case.true_user_data["data"], case.data_cfg))
+        opts.append(stats["opt_value"]), means.append(float(data.double().mean())), stds.append(float(data.double().std()))
+        print(f"  noise seed {seed}: history {hists[-1]}, psnr {psnrs[-1]:.4f}", flush=True)
+    from breaching_amd.cases import parameter_checksum
+
+    np.savez_compressed(os.path.join(GOLDEN, "attack_seethrough_noise.npz"), history=np.stack(hists), psnr=np.asarray(psnrs),
+                        opt_value=np.asarray(opts), rec_mean=np.asarray(means), rec_std=np.asarray(stds), seeds=np.asarray(NOISE_SEEDS),
+                        model_checksum=np.float64(parameter_checksum(case.model)), labels=rec["labels"].numpy())
 
 
 def golden_seethrough_b8():
@@ -947,8 +1041,9 @@ STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_sc
              resnet18=golden_resnet18, seethrough=golden_seethrough, tag=golden_tag,
              variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg, multiquery=golden_multiquery,
              resnet18_long=golden_resnet18_long, seethrough_b8=golden_seethrough_b8, tag_bert_base=golden_tag_bert_base,
-             pearlmutter=golden_pearlmutter, resnet18_24k=golden_resnet18_24k)
-SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base", "resnet18_24k")  # hours of CPU: only run when asked for by name
+             pearlmutter=golden_pearlmutter, resnet18_24k=golden_resnet18_24k, seethrough_noise=golden_seethrough_noise,
+             resnet18_long_signs=golden_resnet18_long_signs)
+SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base", "resnet18_24k", "seethrough_noise", "resnet18_long_signs")  # hours of CPU: only run when asked for by name
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()

@@ -27,11 +27,11 @@ import sys
 
 FAMILIES = [  # first match wins
     ("ours: kernel A (gm_*)", r"gm_(fwd|bwd|finalize|pack)_kernel"),
-    ("ours: kernel B/C, commit (step, tv, loss)", r"candidate_step_kernel|tv_norm_kernel|loss_commit_kernel|grad_sumsq|state_reset"),
+    ("ours: kernel B/C, commit (step, tv, loss)", r"candidate_step_kernel|tv_norm_kernel|loss_commit_kernel|grad_sumsq|grad_norm_finalize|state_reset"),
     ("ours: kernel D (bn_sums/finalize/bwd)", r"bn_sums_kernel|bn_finalize_kernel|bn_bwd_kernel|bn_bwd_acc_kernel"),
     ("ours: kernel E (bn_eval_*)", r"bn_eval_"),
-    ("ours: kernel F (ln_*)", r"\bln_(fwd|bwd)"),
-    ("ours: multi-tensor (mt_*)", r"mt_kernel|orthogonality_kernel|psnr_mse_kernel|feature_"),
+    ("ours: kernel F (ln_*)", r"ln_(fwd|bwd)"),
+    ("ours: multi-tensor (mt_*)", r"mt_kernel|orthogonality_kernel|psnr_mse_kernel|psnr_finalize"),
     ("runtime: copyBuffer / fillBuffer", r"__amd_rocclr_"),
     ("MIOpen: Winograd / asm direct conv", r"miopenSp3AsmConv|miopenGcnAsm|gcnAsmConv|conv\d+x\d+u|MIOpenConv"),
     ("MIOpen: Im2Col / Col2Im", r"Im2d2Col|Col2Im|Im3d2Col|Col2Im3d"),

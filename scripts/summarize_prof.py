@@ -4,8 +4,12 @@
 """
 import csv, os, sys, collections
 
+# every kernel of libbreach_hip.so: A (gm_*), B / commit (candidate_step, loss_commit, grad_sumsq, state_reset), C (tv_norm),
+# D (bn_sums / bn_finalize / bn_bwd / bn_bwd_acc), E (bn_eval_*), F (ln_*), multi-tensor and metric kernels
 OURS = ("gm_fwd_kernel", "gm_bwd_kernel", "gm_finalize_kernel", "tv_norm_kernel", "candidate_step_kernel", "loss_commit_kernel",
-        "bn_sums_kernel", "bn_finalize_kernel", "bn_bwd_kernel", "bn_bwd_acc_kernel", "mt_kernel", "orthogonality_kernel", "psnr_mse_kernel", "grad_sumsq", "gm_pack_kernel", "state_reset")
+        "bn_sums_kernel", "bn_finalize_kernel", "bn_bwd_kernel", "bn_bwd_acc_kernel", "mt_kernel", "orthogonality_kernel", "psnr_mse_kernel",
+        "grad_sumsq", "gm_pack_kernel", "state_reset", "bn_eval_fwd_kernel", "bn_eval_bwd_kernel", "bn_eval_bwd_bwd_kernel",
+        "bn_eval_combine_kernel", "ln_fwd_kernel", "ln_bwd_", "grad_norm_finalize_kernel", "psnr_finalize_kernel")
 src, out = sys.argv[1], sys.argv[2]
 counter = sys.argv[3] if len(sys.argv) > 3 else None
 files = {f: os.path.join(src, f) for f in os.listdir(src)}

@@ -414,6 +414,75 @@ def test_trials_in_flight_match_sequential_trials():
     assert stats_par["execution"]["trials"] == {t: "hipGraph replay" for t in range(3)} == stats_seq["execution"]["trials"]
 
 
+def test_trials_in_flight_share_priors_with_per_trial_state():
+    """What concurrent trials actually share: the `legacy` family -- soft sign, DeepInversion
+    (producer-side statistics, the backward term riding in kernel E's launch, per-trial sums buffers and tickets, per-pass
+    coefficient records hanging off the SHARED BatchNorm modules), feature hooks on the shared last linear layer, double-
+    opponent TV with general exponents -- four restarts, four in flight vs strictly one after the other.  Every trial's
+    history, the winner and its candidate agree (run-vs-run limits of conftest); all four iterations ran as graph replays.
+    reference: regularizers.py:23-60,203-230; optimization_based_attack.py:70-78."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case
+    from conftest import assert_same_attack
+
+    over = ["optim.max_iterations=14", "optim.callback=7", "restarts.num_trials=4", "init=randn",
+            "regularization.deep_inversion.scale=0.001", "regularization.features.scale=0.1"]
+    case = build_case("convnet", "CIFAR10", 2, device="cuda:0", provide_buffers=True)
+    runs = {}
+    for width in (1, 4):
+        rec, stats, attacker = _attack(case, get_attack_config("legacy", over + [f"impl.trials_in_flight={width}"]), None, seed=3)
+        assert sorted(type(r).__name__ for r in attacker.regularizers) == ["HipDeepInversion", "HipFeatureRegularization", "HipTotalVariation"]
+        assert stats["execution"]["trials"] == {t: "hipGraph replay" for t in range(4)}
+        taps = [h for r in attacker.regularizers if type(r).__name__ == "HipDeepInversion" for h in r.losses[0]]
+        assert taps and all(h.in_producer and h.fed for h in taps)  # statistics and backward term inside kernel E's launches
+        runs[width] = (rec["data"], stats)
+    histories = [runs[4][1][f"Trial_{t}_Val"] for t in range(4)]
+    assert all(len(h) == 14 for h in histories)
+    assert len({round(h[0], 6) for h in histories}) == 4  # four different starting points, not one trial four times
+    assert_same_attack(runs[4], runs[1])
+
+
+def test_device_langevin_noise_under_graph_replay(golden_dir):
+    """see-through-gradients with the shipped Langevin noise drawn ON THE DEVICE inside the replayed iteration
+    (`torch.randn_like` captured into the hipGraph; optimization_based_attack.py:167-170).  (1) The trial runs as graph
+    replays; (2) the captured generator offsets advance: the same seed reproduces the run bit for bit, another seed gives
+    another run, and within a run consecutive noise draws differ; (3) six device-noise runs sit inside the reference's OWN
+    envelope over five noise streams (fixture attack_seethrough_noise.npz, unmodified reference on CPU): per iteration within
+    the reference's range widened by 3x its spread (floor: north_star's 1e-4), mean PSNR within 0.1 dB of the reference's."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case, initial_candidate, parameter_checksum, psnr
+
+    gold = np.load(os.path.join(golden_dir, "attack_seethrough_noise.npz"))
+    case = build_case("resnet50", "ImageNet", 2, device="cuda:0", provide_buffers=True)
+    assert parameter_checksum(case.model) == pytest.approx(float(gold["model_checksum"]), rel=1e-8)
+    x0 = initial_candidate(case.data_cfg, 2)
+    its = gold["history"].shape[1]
+    cfg = get_attack_config("seethroughgradients", [f"optim.max_iterations={its}", "optim.warmup=2", "optim.callback=4"])
+    assert cfg.optim.langevin_noise == 0.01
+
+    def run(seed):
+        rec, stats, attacker = _attack(case, cfg, x0, seed=seed)
+        assert attacker.last_trial_execution == "hipGraph replay"
+        return np.asarray(stats["Trial_0_Val"]), rec["data"].detach().clone(), psnr(rec["data"], case.true_user_data["data"], case.data_cfg)
+
+    runs = {seed: run(seed) for seed in (21, 22, 23, 24, 25, 26)}
+    again = run(21)
+    assert np.array_equal(again[0], runs[21][0]) and torch.equal(again[1], runs[21][1])  # same seed: same captured noise stream
+    assert not torch.equal(runs[21][1], runs[22][1])                                      # another seed: another stream
+    ref = gold["history"]
+    lo, hi, spread = ref.min(axis=0), ref.max(axis=0), ref.max(axis=0) - ref.min(axis=0)
+    slack = np.maximum(3.0 * spread, LOSS_RTOL * np.abs(ref.mean(axis=0)))
+    hist = np.stack([r[0] for r in runs.values()])
+    print("  reference range", lo, hi, "\n  hip range      ", hist.min(axis=0), hist.max(axis=0))
+    assert hist.shape == (6, its)
+    assert (hist >= lo - slack).all() and (hist <= hi + slack).all()
+    # the noise matters at all: six device streams do not collapse onto one trajectory after the first noisy step
+    assert np.ptp(hist[:, -1]) > 0
+    mean_psnr = float(np.mean([r[2] for r in runs.values()]))
+    print(f"  PSNR: hip mean {mean_psnr:.4f} dB, reference mean {gold['psnr'].mean():.4f} dB (range {gold['psnr'].min():.4f} .. {gold['psnr'].max():.4f})")
+    assert abs(mean_psnr - float(gold["psnr"].mean())) <= PSNR_TOL_DB
+
+
 def test_label_recovery_strategies_match_reference(golden_dir):
     """`_recover_label_information` (base_attack.py:305-475) when the user withholds labels.  Strategies that pad with
     random labels (iDLG / analytic on batches with repeated labels) are compared on their deterministic part only."""
