@@ -50,10 +50,31 @@ def _module_rank(item):
 RUN_VS_RUN = dict(history_rtol=1e-4, opt_value_rel=1e-3, pixel_tol=1e-3, pixel_fraction=0.999)
 
 
-def assert_same_attack(run_a, run_b, stats_keys=None):
-    """`run_x = (reconstruction tensor, stats)` of two executions of the same attack from the same start."""
+def runs_identical(run_a, run_b):
+    """Bit for bit: every loss history, opt_value and every pixel of the reconstruction."""
+    import torch
+
+    (rec_a, stats_a), (rec_b, stats_b) = run_a, run_b
+    keys = sorted(k for k in stats_a if k.startswith("Trial_"))
+    return (keys == sorted(k for k in stats_b if k.startswith("Trial_")) and all(list(stats_a[k]) == list(stats_b[k]) for k in keys)
+            and stats_a["opt_value"] == stats_b["opt_value"] and torch.equal(rec_a.detach().cpu(), rec_b.detach().cpu()))
+
+
+def assert_same_attack(run_a, run_b, stats_keys=None, control=None):
+    """`run_x = (reconstruction tensor, stats)` of two executions of the same attack from the same start.
+
+    `control`: a SECOND execution of run_b's own configuration.  When the control reproduces run_b bit for bit -- the vendor
+    kernels are deterministic on this box for this workload, which is what was measured on every box so far -- run_a has to be
+    bit-identical as well: a replay / staleness defect of any size fails.  Only when the control itself wobbles do the
+    RUN_VS_RUN limits below apply (and the test says so)."""
     import numpy as np
 
+    if control is not None:
+        if runs_identical(control, run_b):
+            assert runs_identical(run_a, run_b), "the control run reproduced bit for bit, the run under test did not"
+            return
+        print("  [run-vs-run] the control run of the same configuration was NOT bit-identical on this box: vendor-kernel wobble; "
+              "comparing within RUN_VS_RUN limits")
     (rec_a, stats_a), (rec_b, stats_b) = run_a, run_b
     keys = stats_keys if stats_keys is not None else sorted(k for k in stats_a if k.startswith("Trial_"))
     assert keys and sorted(k for k in stats_b if k.startswith("Trial_")) == sorted(k for k in stats_a if k.startswith("Trial_"))

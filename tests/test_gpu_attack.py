@@ -406,11 +406,12 @@ def test_trials_in_flight_match_sequential_trials():
             "restarts.num_trials=3", "restarts.scoring=euclidean", "optim.callback=5"]
     case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
     rec_seq, stats_seq, _ = _attack(case, get_attack_config("invertinggradients", over + ["impl.trials_in_flight=1"]), None, seed=3)
+    rec_ctl, stats_ctl, _ = _attack(case, get_attack_config("invertinggradients", over + ["impl.trials_in_flight=1"]), None, seed=3)
     rec_par, stats_par, _ = _attack(case, get_attack_config("invertinggradients", over + ["impl.trials_in_flight=3"]), None, seed=3)
     from conftest import assert_same_attack
 
     assert sorted(k for k in stats_par if k.startswith("Trial_")) == [f"Trial_{t}_Val" for t in range(3)]
-    assert_same_attack((rec_par["data"], stats_par), (rec_seq["data"], stats_seq))
+    assert_same_attack((rec_par["data"], stats_par), (rec_seq["data"], stats_seq), control=(rec_ctl["data"], stats_ctl))
     assert stats_par["execution"]["trials"] == {t: "hipGraph replay" for t in range(3)} == stats_seq["execution"]["trials"]
 
 
@@ -429,8 +430,8 @@ def test_trials_in_flight_share_priors_with_per_trial_state():
             "regularization.deep_inversion.scale=0.001", "regularization.features.scale=0.1"]
     case = build_case("convnet", "CIFAR10", 2, device="cuda:0", provide_buffers=True)
     runs = {}
-    for width in (1, 4):
-        rec, stats, attacker = _attack(case, get_attack_config("legacy", over + [f"impl.trials_in_flight={width}"]), None, seed=3)
+    for width in (1, "control", 4):
+        rec, stats, attacker = _attack(case, get_attack_config("legacy", over + [f"impl.trials_in_flight={1 if width == 'control' else width}"]), None, seed=3)
         assert sorted(type(r).__name__ for r in attacker.regularizers) == ["HipDeepInversion", "HipFeatureRegularization", "HipTotalVariation"]
         assert stats["execution"]["trials"] == {t: "hipGraph replay" for t in range(4)}
         taps = [h for r in attacker.regularizers if type(r).__name__ == "HipDeepInversion" for h in r.losses[0]]
@@ -439,18 +440,36 @@ def test_trials_in_flight_share_priors_with_per_trial_state():
     histories = [runs[4][1][f"Trial_{t}_Val"] for t in range(4)]
     assert all(len(h) == 14 for h in histories)
     assert len({round(h[0], 6) for h in histories}) == 4  # four different starting points, not one trial four times
-    assert_same_attack(runs[4], runs[1])
+    assert_same_attack(runs[4], runs[1], control=runs["control"])
 
 
 def test_device_langevin_noise_under_graph_replay(golden_dir):
     """see-through-gradients with the shipped Langevin noise drawn ON THE DEVICE inside the replayed iteration
-    (`torch.randn_like` captured into the hipGraph; optimization_based_attack.py:167-170).  (1) The trial runs as graph
-    replays; (2) the captured generator offsets advance: the same seed reproduces the run bit for bit, another seed gives
-    another run, and within a run consecutive noise draws differ; (3) six device-noise runs sit inside the reference's OWN
-    envelope over five noise streams (fixture attack_seethrough_noise.npz, unmodified reference on CPU): per iteration within
-    the reference's range widened by 3x its spread (floor: north_star's 1e-4), mean PSNR within 0.1 dB of the reference's."""
+    (`torch.randn_like` captured into the hipGraph; optimization_based_attack.py:167-170).
+    (1) ConvNet (a workload whose GPU runs are bit-reproducible, so the noise stream is the only thing that can differ): the
+        trial runs as graph replays; the same seed reproduces the run bit for bit, another seed gives another run -- the
+        captured generator offsets advance with every replay and follow the seed.
+    (2) ResNet-50, 2 images: six device-noise runs sit inside the reference's OWN envelope over five noise streams (fixture
+        attack_seethrough_noise.npz, unmodified reference on CPU): per iteration within the reference's range widened by 3x
+        its spread (floor: north_star's 1e-4, which is what the noise-free first two iterations are held to), mean PSNR within
+        0.1 dB of the reference's."""
     from breaching_amd import get_attack_config
     from breaching_amd.cases import build_case, initial_candidate, parameter_checksum, psnr
+
+    small = build_case("convnet", "CIFAR10", 2, device="cuda:0", provide_buffers=True)
+    small_cfg = get_attack_config("seethroughgradients", ["optim.max_iterations=12", "optim.warmup=2", "optim.callback=4"])
+    assert small_cfg.optim.langevin_noise == 0.01
+    xs = initial_candidate(small.data_cfg, 2, seed=6)
+
+    def run_small(seed):
+        rec, stats, attacker = _attack(small, small_cfg, xs, seed=seed)
+        assert attacker.last_trial_execution == "hipGraph replay"
+        return np.asarray(stats["Trial_0_Val"]), rec["data"].detach().clone()
+
+    a, a_again, b = run_small(21), run_small(21), run_small(22)
+    assert np.array_equal(a[0], a_again[0]) and torch.equal(a[1], a_again[1])  # same seed: same captured noise stream
+    assert not torch.equal(a[1], b[1]) and not np.array_equal(a[0][3:], b[0][3:])  # another seed: another stream
+    assert np.array_equal(a[0][:1], b[0][:1])                                   # (the first loss is computed before any noise)
 
     gold = np.load(os.path.join(golden_dir, "attack_seethrough_noise.npz"))
     case = build_case("resnet50", "ImageNet", 2, device="cuda:0", provide_buffers=True)
@@ -458,27 +477,22 @@ def test_device_langevin_noise_under_graph_replay(golden_dir):
     x0 = initial_candidate(case.data_cfg, 2)
     its = gold["history"].shape[1]
     cfg = get_attack_config("seethroughgradients", [f"optim.max_iterations={its}", "optim.warmup=2", "optim.callback=4"])
-    assert cfg.optim.langevin_noise == 0.01
 
     def run(seed):
         rec, stats, attacker = _attack(case, cfg, x0, seed=seed)
         assert attacker.last_trial_execution == "hipGraph replay"
-        return np.asarray(stats["Trial_0_Val"]), rec["data"].detach().clone(), psnr(rec["data"], case.true_user_data["data"], case.data_cfg)
+        return np.asarray(stats["Trial_0_Val"]), psnr(rec["data"], case.true_user_data["data"], case.data_cfg)
 
-    runs = {seed: run(seed) for seed in (21, 22, 23, 24, 25, 26)}
-    again = run(21)
-    assert np.array_equal(again[0], runs[21][0]) and torch.equal(again[1], runs[21][1])  # same seed: same captured noise stream
-    assert not torch.equal(runs[21][1], runs[22][1])                                      # another seed: another stream
+    runs = [run(seed) for seed in (21, 22, 23, 24, 25, 26)]
     ref = gold["history"]
     lo, hi, spread = ref.min(axis=0), ref.max(axis=0), ref.max(axis=0) - ref.min(axis=0)
     slack = np.maximum(3.0 * spread, LOSS_RTOL * np.abs(ref.mean(axis=0)))
-    hist = np.stack([r[0] for r in runs.values()])
+    hist = np.stack([r[0] for r in runs])
     print("  reference range", lo, hi, "\n  hip range      ", hist.min(axis=0), hist.max(axis=0))
     assert hist.shape == (6, its)
     assert (hist >= lo - slack).all() and (hist <= hi + slack).all()
-    # the noise matters at all: six device streams do not collapse onto one trajectory after the first noisy step
-    assert np.ptp(hist[:, -1]) > 0
-    mean_psnr = float(np.mean([r[2] for r in runs.values()]))
+    assert np.ptp(hist[:, -1]) > 0  # six device streams do not collapse onto one trajectory
+    mean_psnr = float(np.mean([r[1] for r in runs]))
     print(f"  PSNR: hip mean {mean_psnr:.4f} dB, reference mean {gold['psnr'].mean():.4f} dB (range {gold['psnr'].min():.4f} .. {gold['psnr'].max():.4f})")
     assert abs(mean_psnr - float(gold["psnr"].mean())) <= PSNR_TOL_DB
 
@@ -544,13 +558,14 @@ def test_graph_replay_and_eager_launches_give_the_same_trajectory():
     from conftest import assert_same_attack
 
     runs = {}
-    for flag in (True, False):
-        rec, stats, _ = _attack(case, get_attack_config("invertinggradients", over + [f"impl.hip_graph={flag}"]), x0)
+    for flag in (True, False, "control"):  # control = a second eager run
+        rec, stats, _ = _attack(case, get_attack_config("invertinggradients", over + [f"impl.hip_graph={flag is True}"]), x0)
         runs[flag] = (rec["data"], stats)
     assert runs[True][1]["execution"]["trials"] == {0: "hipGraph replay"}
-    assert runs[False][1]["execution"]["trials"] == {0: "eager launches (graph replay switched off)"}
+    assert runs[False][1]["execution"]["trials"] == {0: "eager launches (graph replay switched off)"} == runs["control"][1]["execution"]["trials"]
     assert len(runs[True][1]["Trial_0_Val"]) == 15
-    assert_same_attack(runs[True], runs[False])
+    # strict when a second eager run reproduces the first bit for bit (it did on every box measured), RUN_VS_RUN otherwise
+    assert_same_attack(runs[True], runs[False], control=runs["control"])
 
 
 def test_deep_leakage_joint_lbfgs(golden_dir):

@@ -428,7 +428,10 @@ def test_reconstruct_shards_trials_over_worker_processes_and_matches_one_rank():
                 torch.manual_seed(3)
                 rec_again, stats_again = attacker.reconstruct(case.server_payload, shared, {})
                 assert stats_again["opt_value"] == pytest.approx(stats["opt_value"], rel=RUN_VS_RUN["opt_value_rel"])
-                assert stats["execution"]["pool"] == dict(backend="gloo", world=2, devices=[0, 0])
+                pool = stats["execution"]["pool"]
+                assert {k: pool[k] for k in ("backend", "world", "devices")} == dict(backend="gloo", world=2, devices=[0, 0])
+                # where the wall time outside the trials went (what an 8-GPU run will be read by): all present, all sane
+                assert pool["pool_start_s"] > 0 and pool["job_ship_s"] >= 0 and pool["trials_wait_s"] >= 0 and pool["select_s"] > 0
                 assert stats["execution"]["pool_fallback"] is None and stats["execution"]["world"] == 2
                 # the launch mode of every trial, the worker's included, reaches the caller
                 assert stats["execution"]["trials"] == {t: "hipGraph replay" for t in range(4)}
@@ -442,6 +445,46 @@ def test_reconstruct_shards_trials_over_worker_processes_and_matches_one_rank():
     (rec1, stats1), (rec2, stats2) = results["[0]"], results["[0, 0]"]
     assert sorted(stats2) == sorted(stats1) == sorted([f"Trial_{t}_Val" for t in range(4)] + ["opt_value", "execution"])
     assert_same_attack((rec2, stats2), (rec1, stats1))
+
+
+@pytest.mark.trial_pool
+def test_configs3_shape_32_restarts_over_four_ranks_two_groups_of_four_each():
+    """BASELINE configs[3]'s shape on one GPU: num_trials=32 over FOUR ranks (the caller + three workers, all on cuda:0, gloo) =
+    8 trials per rank, which every rank runs as two groups of four trials in flight -- the arrangement an 8-GPU node runs with
+    one rank per GPU.  Every one of the 32 histories, the winner and its candidate equal the single-rank run (8 groups of
+    four, one after the other); every trial was a graph replay; the pool reports its timing.  Short smooth ConvNet attack.
+    optimization_based_attack.py:70-78 (the sequential loop being sharded)."""
+    import torch.distributed as dist
+    from conftest import assert_same_attack
+
+    import breaching_amd
+    from breaching_amd.cases import build_case
+
+    over = ["objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft", "optim.max_iterations=8",
+            "restarts.num_trials=32", "restarts.scoring=euclidean", "optim.callback=4", "impl.trial_pool=required"]
+    case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
+    setup = dict(device=torch.device("cuda:0"), dtype=torch.float)
+    results = {}
+    for devices in ("[0]", "[0, 0, 0, 0]"):
+        cfg = breaching_amd.get_attack_config("invertinggradients", over + [f"impl.trial_devices={devices}"])
+        attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
+        try:
+            torch.manual_seed(5)
+            shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+            rec, stats = attacker.reconstruct(case.server_payload, shared, {})
+            assert stats["execution"]["trials"] == {t: "hipGraph replay" for t in range(32)}
+            if devices != "[0]":
+                pool = stats["execution"]["pool"]
+                assert pool["world"] == 4 and pool["backend"] == "gloo" and stats["execution"]["world"] == 4
+                print("  pool:", {k: pool[k] for k in ("pool_start_s", "job_ship_s", "trials_wait_s", "select_s")})
+            results[devices] = (rec["data"].cpu(), dict(stats))
+        finally:
+            attacker.close()
+        assert not dist.is_initialized()
+    assert sorted(k for k in results["[0, 0, 0, 0]"][1] if k.startswith("Trial_")) == sorted(f"Trial_{t}_Val" for t in range(32))
+    firsts = {round(results["[0]"][1][f"Trial_{t}_Val"][0], 5) for t in range(32)}
+    assert len(firsts) == 32  # 32 different starting points, each drawn by rank 0 in the reference's order
+    assert_same_attack(results["[0, 0, 0, 0]"], results["[0]"])
 
 
 @pytest.mark.trial_pool
