@@ -237,13 +237,17 @@ def main():
     # One trial: on the caller's stream, like `_fused_loop`.  Several in flight: every one on a side stream of its own, none on
     # the caller's (same layout as HipOptimizationAttacker._run_trial_group, see the measurement quoted there).
     main_stream = torch.cuda.current_stream(device)
-    first_stream = torch.cuda.Stream(device) if args.trials_per_gpu > 1 else main_stream
+    from breaching_amd.streams import calibration_report, side_streams
+
+    # up to four trials: the product's measured choice of side streams (one hardware pipe each); more: plain pool streams
+    side = side_streams(device, args.trials_per_gpu) if args.trials_per_gpu > 1 else []
+    first_stream = side[0] if side else main_stream
     first_stream.wait_stream(main_stream)
     with torch.cuda.stream(first_stream):
         run = FusedTrial(attacker, [x0], labels, rec_models, case.shared_data)
     extra = []
     for j in range(1, args.trials_per_gpu):
-        stream = torch.cuda.Stream(device)
+        stream = side[j]
         stream.wait_stream(torch.cuda.current_stream(device))
         xj = initial_candidate(case.data_cfg, 1, trial=rank + world * j).to(device).requires_grad_(True)
         with torch.cuda.stream(stream):
@@ -481,6 +485,7 @@ def main():
             "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),
             "graph_capture_error": graph_failed,
             "final_objective": state["total"],
+            "trial_streams": calibration_report(device) if args.trials_per_gpu > 1 else None,
             "per_rank_ms_per_step": per_rank_ms,
             "rank_skew": None if not per_rank_ms else round(max(per_rank_ms) / min(per_rank_ms), 4),
             "select_ms": select_ms,

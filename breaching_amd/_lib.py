@@ -117,10 +117,10 @@ _PROTOTYPES = {
          c_int64, POINTER(BnItem), c_int64],
     ),
     "bh_bn_bwd_accumulate": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "bh_bn_eval_fwd": (c_int, [c_void_p] * 7 + [c_int32, c_int32, c_int32, c_void_p]),
+    "bh_bn_eval_fwd": (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "bh_bn_eval_slabs": (c_int32, [c_int32, c_int32, c_int32]),
-    "bh_bn_eval_bwd": (c_int, [c_void_p] * 11 + [c_int32, c_int32, c_int32, c_void_p]),
-    "bh_bn_eval_bwd_bwd": (c_int, [c_void_p] * 12 + [c_int32, c_int32, c_int32, c_void_p]),
+    "bh_bn_eval_bwd": (c_int, [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_void_p]),
+    "bh_bn_eval_bwd_bwd": (c_int, [c_void_p] * 14 + [c_int32, c_int32, c_int32, c_void_p]),
     "bh_ln_fwd": (c_int, [c_void_p] * 6 + [c_int32, c_int32, ctypes.c_float, c_void_p]),
     "bh_ln_bwd": (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_void_p]),
     "bh_ln_bwd_bwd": (c_int, [c_void_p] * 12 + [c_int32, c_int32, c_void_p]),

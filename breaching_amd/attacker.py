@@ -21,7 +21,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from . import _lib, schedules, trials, workers
+from . import _lib, schedules, streams as trial_streams, trials, workers
 from .gm import objective_lookup
 from .priors import HipNormRegularization, HipTotalVariation, launch_tv_norm, regularizer_lookup
 
@@ -194,7 +194,8 @@ class HipOptimizationAttacker:
         # How this call was executed, on the channel callers already read (base_attack.py:45): per-trial launch mode of
         # this rank's trials, the pool that shared the trials (backend, world, devices) or why there was none.
         stats["execution"] = dict(trials=stats.pop("execution_trials"), pool=pool.describe() if pool is not None else None,
-                                  pool_fallback=getattr(self, "_pool_fallback", None), world=shard.world)
+                                  pool_fallback=getattr(self, "_pool_fallback", None), world=shard.world,
+                                  trial_streams=trial_streams.calibration_report(self.setup["device"]))
         reconstructed_data = self._package(optimal, labels)
         if server_payload[0]["metadata"].modality == "text":
             raw = reconstructed_data["data"]
@@ -341,7 +342,7 @@ class HipOptimizationAttacker:
                 raise NotImplementedError("impl.JIT (torch.jit script/trace of the victim model) is not supported.")
             bn_mode = fast_eval_bn_mode(self.cfg)
             if bn_mode is not None:
-                use_affine_eval_batchnorm(new_model, bn_mode)
+                use_affine_eval_batchnorm(new_model, bn_mode, fuse_epilogue=fuse_bn_relu_enabled(self.cfg))
             if fast_layer_norm_enabled(self.cfg):
                 use_hip_layernorm(new_model)
             models.append(new_model)
@@ -629,8 +630,11 @@ class HipOptimizationAttacker:
         # stream and three on side streams runs at ~120 iterations/s instead of ~430 -- every replay then serialises against
         # the other trials' streams; with all four on side streams the rate is 428 whether or not an attack ran before
         # (and the same 430-440 in a fresh process).  GPU_MAX_HW_QUEUES=8 (breaching_amd/__init__.py) leaves a hardware
-        # queue for each of them next to the caller's.
-        streams = {t: torch.cuda.Stream(device) for t in group}
+        # queue for each of them next to the caller's.  WHICH side streams matters as much: two busy streams on one of the four
+        # hardware compute pipes run slower than one after the other (round 4, profiles/r4_inflight_pipes_probe.jsonl: four
+        # trials 526 it/s on distinct pipes, 173 with one collision), so the streams are picked by measurement, once per process
+        # and device, and reused by every later group (breaching_amd/streams.py).
+        streams = dict(zip(group, trial_streams.side_streams(device, len(group))))
         runs = {}
         for t in group:
             candidates = list(init_states[t])
@@ -891,26 +895,32 @@ class _EvalBNFunction(torch.autograd.Function):
     launch again and itself differentiable -- the attack needs the derivative of the first-order pass (objectives.py:40-46
     under create_graph=True, then optimization_based_attack.py:160).
 
+    Epilogue: with `residual` and / or `relu` the launch computes y = relu(x * s_c + t_c + residual) -- the tail of a ResNet
+    block (`_PendingBatchNorm` decides when) -- and the two backward orders carry the ReLU mask (read back from y) and the
+    residual's gradient.
+
     With `tap` (a DeepInversion tap of this layer, priors._BnInputTap) the node has a second, 0-dim output: the token through
     which the prior's statistic node sends back d objective / d total.  When that token gradient arrives together with gy,
     the backward launch adds the prior's term gout * (A_c + B_c * x) to gx (it reads x anyway): the prior's backward costs
     no launch and no traffic of its own (regularizers.py:222-227 / deepinversion.py:93-103, math only)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, inv_std, mean_inv, stats=None, tap=None):
+    def forward(ctx, x, weight, bias, inv_std, mean_inv, stats=None, tap=None, residual=None, relu=False):
         """`stats`: fp64 view of 2 * C * S words that receives sum(x), sum(x^2) per (channel, slab) -- kernel D's input."""
         lib = _lib.load()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         xk = _vector_ready(x.detach(), hw)
+        rk = None if residual is None else _vector_ready(residual.detach().to(torch.float32), hw)
         y = torch.empty_like(xk)
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_fwd(_lib.ptr(xk), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(inv_std), _lib.ptr(mean_inv),
-                                          _lib.ptr(y), _lib.ptr(stats), B, C, hw, _lib.current_stream_handle(x.device)),
-                       "bh_bn_eval_fwd")
-        # the INPUT itself is saved (not the detached kernel view): the backward below is differentiable with respect to it
-        ctx.save_for_backward(x, weight, inv_std, mean_inv)
-        ctx.has_bias = bias is not None
+                                          _lib.ptr(y), _lib.ptr(stats), _lib.ptr(rk), int(bool(relu)), B, C, hw,
+                                          _lib.current_stream_handle(x.device)), "bh_bn_eval_fwd")
+        # the INPUT itself is saved (not the detached kernel view): the backward below is differentiable with respect to it;
+        # with a ReLU the OUTPUT is saved too -- its sign is the mask of both backward orders
+        ctx.save_for_backward(x, weight, inv_std, mean_inv, *([y] if relu else []))
+        ctx.has_bias, ctx.relu, ctx.has_residual = bias is not None, bool(relu), residual is not None
         ctx.tap = None
         if tap is None:
             return y
@@ -920,11 +930,13 @@ class _EvalBNFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy, g_token=None):
-        x, weight, inv_std, mean_inv = ctx.saved_tensors
+        x, weight, inv_std, mean_inv, *rest = ctx.saved_tensors
+        mask = rest[0].detach() if ctx.relu else None  # a constant of every order (ReLU'' = 0 almost everywhere)
+        none = (None,) * 9
         if g_token is None or ctx.tap is None:
             if gy is None:
-                return None, None, None, None, None, None, None
-            gx, gw, gb = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv)
+                return none
+            gx, gw, gb, gr = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv, mask, None, ctx.has_residual)
         else:
             if torch.is_grad_enabled():
                 raise NotImplementedError("The DeepInversion term fused into the BatchNorm backward supports no create_graph "
@@ -934,23 +946,27 @@ class _EvalBNFunction(torch.autograd.Function):
             if gy is None:
                 gy = torch.zeros_like(x)
             gout = g_token.detach().reshape(1).to(torch.float32)
-            gx, gw, gb = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv, (coef_ptr, gout, record.coef))
-        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None, None
+            gx, gw, gb, gr = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv, mask, (coef_ptr, gout, record.coef), ctx.has_residual)
+        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None, None, gr, None
 
 
 class _EvalBNGradFunction(torch.autograd.Function):
-    """(gy, x, weight) -> (gx, gw, gb) in one launch (bh_bn_eval_bwd); backward = the derivative of that map in one launch
-    (bh_bn_eval_bwd_bwd).  PyTorch's decomposition of the same three orders is ~35 launches per layer.  `tap` = (address of
-    the layer's (A_c, B_c) pairs, gout, owner of that memory): gx additionally receives gout * (A_c + B_c * x)."""
+    """(gy, x, weight) -> (gx, gw, gb, g_residual) in one launch (bh_bn_eval_bwd); backward = the derivative of that map in one
+    launch (bh_bn_eval_bwd_bwd).  PyTorch's decomposition of the same three orders is ~35 launches per layer (+ 6 for a ReLU).
+    `mask`: the forward output when the forward applied a ReLU (gy is masked by [y > 0] first); `tap` = (address of the layer's
+    (A_c, B_c) pairs, gout, owner of that memory): gx additionally receives gout * (A_c + B_c * x); `want_residual`: also
+    return the masked gradient itself, the gradient of the forward's residual input."""
 
     @staticmethod
-    def forward(ctx, gy, x, weight, inv_std, mean_inv, tap=None):
+    def forward(ctx, gy, x, weight, inv_std, mean_inv, mask=None, tap=None, want_residual=False):
         lib = _lib.load()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         gyk = _vector_ready(gy.detach().to(torch.float32), hw)
         xk = _vector_ready(x.detach(), hw)
+        mk = None if mask is None else _vector_ready(mask.detach(), hw)
         gx = torch.empty_like(xk)
+        gr = torch.empty_like(xk) if want_residual else None
         gw = torch.empty(C, dtype=torch.float32, device=x.device)
         gb = torch.empty(C, dtype=torch.float32, device=x.device)
         slabs = lib.bh_bn_eval_slabs(B, C, hw)
@@ -958,41 +974,158 @@ class _EvalBNGradFunction(torch.autograd.Function):
         coef_ptr, gout = (tap[0], _lib.ptr(tap[1])) if tap is not None else (_lib.ptr(None), _lib.ptr(None))
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_bwd(_lib.ptr(gyk), _lib.ptr(xk), _lib.ptr(weight), _lib.ptr(inv_std), _lib.ptr(mean_inv),
-                                          _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), coef_ptr, gout, B, C, hw,
-                                          _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd")
-        ctx.save_for_backward(gyk, xk, weight, inv_std, mean_inv)
+                                          _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), coef_ptr, gout, _lib.ptr(mk), _lib.ptr(gr),
+                                          B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd")
+        ctx.save_for_backward(gyk, xk, weight, inv_std, mean_inv, *([mk] if mk is not None else []))
         ctx.set_materialize_grads(False)
-        ctx.had_tap = tap is not None
-        return gx, gw, gb
+        ctx.had_tap, ctx.masked = tap is not None, mk is not None
+        return gx, gw, gb, gr
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, ggx, ggw, ggb):
+    def backward(ctx, ggx, ggw, ggb, ggr):
         lib = _lib.load()
-        gy, x, weight, inv_std, mean_inv = ctx.saved_tensors
-        if ggx is None and ggw is None and ggb is None:
-            return None, None, None, None, None, None
+        gy, x, weight, inv_std, mean_inv, *rest = ctx.saved_tensors
+        mask = rest[0] if ctx.masked else None
+        none = (None,) * 8
+        if ggx is None and ggw is None and ggb is None and ggr is None:
+            return none
         if ctx.had_tap:
             raise NotImplementedError("No derivative of the BatchNorm backward with the DeepInversion term fused in.")
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
-        ggx = None if ggx is None else ggx.to(torch.float32).contiguous()
+        ggx = None if ggx is None else _vector_ready(ggx.to(torch.float32), hw)
+        ggr = None if ggr is None else _vector_ready(ggr.to(torch.float32), hw)
         ggw = None if ggw is None else ggw.to(torch.float32).contiguous()
         ggb = None if ggb is None else ggb.to(torch.float32).contiguous()
         d_gy = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         d_x = torch.empty_like(x) if (ctx.needs_input_grad[1] and ggw is not None) else None
         d_w = torch.empty(C, dtype=torch.float32, device=x.device) if (weight is not None and ctx.needs_input_grad[2] and ggx is not None) else None
         if d_gy is None and d_x is None and d_w is None:
-            return None, None, None, None, None, None
-        if ggx is not None and hw % 4 == 0 and ggx.data_ptr() % 16:
-            ggx = ggx.clone()
+            return none
         slabs = lib.bh_bn_eval_slabs(B, C, hw)
         ws = torch.empty(C * slabs, dtype=torch.float64, device=x.device) if slabs > 1 else None
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_bwd_bwd(_lib.ptr(ggx), _lib.ptr(ggw), _lib.ptr(ggb), _lib.ptr(gy), _lib.ptr(x), _lib.ptr(weight),
                                               _lib.ptr(inv_std), _lib.ptr(mean_inv), _lib.ptr(d_gy), _lib.ptr(d_x), _lib.ptr(d_w),
-                                              _lib.ptr(ws), B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd_bwd")
-        return d_gy, d_x, d_w, None, None, None
+                                              _lib.ptr(ws), _lib.ptr(mask), _lib.ptr(ggr), B, C, hw, _lib.current_stream_handle(x.device)),
+                       "bh_bn_eval_bwd_bwd")
+        return d_gy, d_x, d_w, None, None, None, None, None
+
+
+def _launch_eval_bn(module, x, sink, tap, residual, relu):
+    """One kernel E forward launch of `module` on `x` (+ residual, ReLU); hands the DeepInversion tap its token."""
+    inv_std, mean_inv = module._frozen_statistics()
+    args = (x, module.weight, module.bias, inv_std, mean_inv, sink, tap, residual, relu)
+    if tap is None:
+        return _EvalBNFunction.apply(*args)
+    y, tap.token = _EvalBNFunction.apply(*args)
+    return y
+
+
+_RELU_OUT_OF_PLACE = (torch.relu, torch.nn.functional.relu, torch.Tensor.relu)
+_RELU_IN_PLACE = (torch.relu_, torch.Tensor.relu_, torch.nn.functional.relu_)
+_ADD_OUT_OF_PLACE = (torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Tensor.__radd__)
+_ADD_IN_PLACE = (torch.Tensor.add_, torch.Tensor.__iadd__)
+
+
+class _PendingBatchNorm(torch.Tensor):
+    """The not-yet-launched output of an eval-mode BatchNorm on kernel E: a metadata-only tensor that waits for its first
+    consumer.  `+ identity` / `+= identity` is absorbed as the launch's residual, `relu` / `relu_` launches
+    y = relu(x * s + t + residual) in one kernel; any other use launches the plain affine map (then the residual add, if one
+    was absorbed) and carries on with an ordinary tensor.  Works on arbitrary Python `forward` code (torchvision-style
+    BasicBlock / Bottleneck included) without tracing or rewriting the victim model; in-place forms update this object, so
+    code that does not rebind the result (`self.relu(out)` with inplace=True, `out.add_(identity)`) sees the right values.
+
+    reference: none -- the reference runs the victim model as it is (objectives.py:36-46); this is launch-count reduction for
+    the attacker's private model copy (~110 of ~717 launches per ResNet-18 iteration, profiles/r4_op_attribution.txt)."""
+
+    @staticmethod
+    def __new__(cls, module, x, sink, tap):
+        self = torch.Tensor._make_wrapper_subclass(cls, x.shape, dtype=x.dtype, device=x.device, requires_grad=False)
+        self._module, self._x, self._sink, self._tap = module, x, sink, tap
+        self._residual, self._value = None, None
+        return self
+
+    def launch(self, relu=False):
+        """Run the kernel now (the only place this object's computation happens)."""
+        return _launch_eval_bn(self._module, self._x, self._sink, self._tap, self._residual, relu)
+
+    def value(self):
+        """The plain (un-fused) result, computed once: affine map, plus the absorbed residual if there is one."""
+        if self._value is None:
+            residual, self._residual = self._residual, None
+            y = self.launch(relu=False)
+            self._value = y if residual is None else y + residual
+        return self._value
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        first = args[0] if args else None
+        fresh = isinstance(first, cls) and first._value is None
+        if fresh and len(args) == 1 and func in _RELU_OUT_OF_PLACE and not kwargs.get("inplace", False):
+            return first.launch(relu=True)  # `first` itself stays pending: a second consumer still gets the un-clamped values
+        if fresh and len(args) == 1 and (func in _RELU_IN_PLACE or (func is torch.nn.functional.relu and kwargs.get("inplace", False))):
+            first._value = first.launch(relu=True)
+            return first._value
+        if func in _ADD_OUT_OF_PLACE or func in _ADD_IN_PLACE:
+            plain_alpha = kwargs.get("alpha", 1) == 1 and set(kwargs) <= {"alpha"} and len(args) == 2
+            if plain_alpha and torch.is_tensor(args[1]) and torch.is_tensor(first):
+                a, b = args
+                if func in _ADD_OUT_OF_PLACE and not (isinstance(a, cls) and a._value is None and a._residual is None):
+                    a, b = b, a  # identity + bn(...)
+                if (isinstance(a, cls) and a._value is None and a._residual is None and b.shape == a.shape and b.dtype == a.dtype
+                        and b.device == a.device):
+                    other = b.value() if isinstance(b, cls) else b
+                    if func in _ADD_IN_PLACE:
+                        if a is args[0]:
+                            a._residual = other
+                            return a
+                    else:
+                        merged = cls(a._module, a._x, a._sink, a._tap)
+                        merged._residual = other
+                        return merged
+        name = getattr(func, "__name__", "")
+        if name == "__get__" and args and isinstance(first, cls) and getattr(getattr(func, "__self__", None), "__name__", "") in (
+                "shape", "dtype", "device", "ndim", "is_cuda", "layout"):
+            with torch._C.DisableTorchFunctionSubclass():  # metadata of the wrapper itself: no launch
+                return func(*args, **kwargs)
+
+        def real(obj):
+            if isinstance(obj, cls):
+                return obj.value()
+            if isinstance(obj, (list, tuple)):
+                return type(obj)(real(o) for o in obj)
+            return obj
+
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*[real(a) for a in args], **{k: real(v) for k, v in kwargs.items()})
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):  # reached only by callers that bypass __torch_function__
+        def real(obj):
+            if isinstance(obj, cls):
+                return obj.value()
+            if isinstance(obj, (list, tuple)):
+                return type(obj)(real(o) for o in obj)
+            return obj
+
+        return func(*[real(a) for a in args], **{k: real(v) for k, v in (kwargs or {}).items()})
+
+    def __repr__(self):
+        return f"_PendingBatchNorm(shape={tuple(self.shape)}, residual={self._residual is not None}, launched={self._value is not None})"
+
+
+def fuse_bn_relu_enabled(cfg=None):
+    """BatchNorm -> (+ residual) -> ReLU in kernel E's launches: on unless BREACH_HIP_FUSE_BN_RELU=0 or cfg.impl.fuse_bn_relu is false."""
+    import os
+
+    env = os.environ.get("BREACH_HIP_FUSE_BN_RELU")
+    if env is not None:
+        return env.strip().lower() not in ("0", "false", "off", "no")
+    flag = _cfg_get(cfg.impl, "fuse_bn_relu", True) if cfg is not None else True
+    return True if flag is None else bool(flag)
 
 
 class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
@@ -1006,6 +1139,7 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
     Training-mode batches, non-4-D, non-fp32 or non-ROCm inputs fall through to the stock / torch path."""
 
     eval_mode = "hip"
+    fuse_epilogue = True  # let the residual add and the ReLU that follow ride in this layer's launches (`_PendingBatchNorm`)
 
     def _runs_on_hip(self, x):
         """Kernel E takes fp32 [B, C, H, W] ROCm activations within its index range (B * HW < 2^31, numel < 2^40), outside
@@ -1034,10 +1168,9 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
             return super().forward(x)
         inv_std, mean_inv = self._frozen_statistics()
         if self._runs_on_hip(x):
-            if tap is None:
-                return _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv, sink)
-            y, tap.token = _EvalBNFunction.apply(x, self.weight, self.bias, inv_std, mean_inv, sink, tap)
-            return y
+            if self.fuse_epilogue and fuse_bn_relu_enabled():
+                return _PendingBatchNorm(self, x, sink, tap)  # launched by its first consumer (relu / + identity / anything)
+            return _launch_eval_bn(self, x, sink, tap, None, False)
         if self.weight is not None:
             scale = self.weight * inv_std
             shift = -(self.weight * mean_inv)
@@ -1060,14 +1193,16 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
         return cached[1], cached[2]
 
 
-def use_affine_eval_batchnorm(model, mode="hip"):
+def use_affine_eval_batchnorm(model, mode="hip", fuse_epilogue=True):
     """Convert every plain BatchNorm2d of `model` in place (idempotent).  On by default; cfg.impl.fast_eval_bn (True / "hip" /
-    "addcmul" / False) or BREACH_HIP_FAST_BN (1 / hip / addcmul / 0) choose the formulation or keep the stock modules."""
+    "addcmul" / False) or BREACH_HIP_FAST_BN (1 / hip / addcmul / 0) choose the formulation or keep the stock modules;
+    `fuse_epilogue` (cfg.impl.fuse_bn_relu / BREACH_HIP_FUSE_BN_RELU): the following residual add and ReLU ride in the launch."""
     for module in model.modules():
         if type(module) is torch.nn.BatchNorm2d:
             module.__class__ = _EvalAffineBatchNorm2d
         if type(module) is _EvalAffineBatchNorm2d:
             module.eval_mode = mode
+            module.fuse_epilogue = bool(fuse_epilogue)
     return model
 
 

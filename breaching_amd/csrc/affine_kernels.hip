@@ -12,6 +12,15 @@
 //   backward of the backward, for incoming (ggx, ggw, ggb):
 //                  d_gy = ggx * s_c + ggw_c * (inv_c * x - mi_c) + ggb_c ;  d_x = ggw_c * inv_c * gy ;
 //                  d_w_c = inv_c * sum(ggx * gy)
+// Optional epilogue (round 4): the residual add and the ReLU that follow the BatchNorm in ResNet blocks ride in the same launches,
+//   forward        z = x * s_c + t_c (+ r) ;  y = relu(z)
+//   backward       gz = gy * [y > 0] ;  gx = gz * s_c ;  gr = gz ;  gw_c, gb_c from gz
+//   backward^2     d_gy = [y > 0] * (ggx * s_c + ggr + ggw_c * (inv_c * x - mi_c) + ggb_c) ;  d_x = ggw_c * inv_c * gz ;
+//                  d_w_c = inv_c * sum(ggx * gz)
+// (ReLU's second derivative vanishes almost everywhere: the mask is a constant of all three orders, read back from y.)  On
+// ResNet-18 that removes ~110 of the ~717 launches of an attack iteration: clamp_min, threshold_backward in both passes, the
+// derivative of threshold_backward and its zero fill, and the residual add (profiles/r4_op_attribution.txt).
+// The backward can also carry the DeepInversion prior's term of this BatchNorm input: gx += gout * (A_c + B_c * x).
 // One workgroup per channel (one wavefront per channel when B * HW is small), fp32 arithmetic with fp64 channel sums, fixed
 // reduction order => run-to-run reproducible.  Bandwidth / latency bound elementwise + reduction work: no MFMA.
 
@@ -76,11 +85,16 @@ __device__ __forceinline__ void channel_sum(double (&v)[K], bool narrow, double*
 __global__ __launch_bounds__(kBlock) void bn_eval_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                              const float* __restrict__ bias, const float* __restrict__ inv_std,
                                                              const float* __restrict__ mean_inv, float* __restrict__ y,
-                                                             double* __restrict__ stats, int B, int C, int HW, int S,
-                                                             int narrow) {
+                                                             double* __restrict__ stats, const float* __restrict__ resid, int relu,
+                                                             int B, int C, int HW, int S, int narrow) {
   __shared__ double lds[bh::kWavesPerBlock * 2];
   const ChannelWalk w = channel_of(C, S, narrow != 0);
   double sums[2] = {0.0, 0.0};  // sum x, sum x^2 of this (channel, slab): only with `stats`
+  // epilogue: (+ residual), ReLU written as (z < 0 ? 0 : z) so that a NaN stays a NaN like torch's clamp_min
+  auto act = [relu](float z, float r) {
+    z += r;
+    return (relu && z < 0.f) ? 0.f : z;
+  };
   if (w.active) {
     const float wc = weight ? weight[w.c] : 1.f;
     const float s = wc * inv_std[w.c];
@@ -96,7 +110,13 @@ __global__ __launch_bounds__(kBlock) void bn_eval_fwd_kernel(const float* __rest
       const size_t at = (size_t)b * cstride + cbase + j;
       if (vec) {
         const float4 q = reinterpret_cast<const float4*>(x)[at];
-        reinterpret_cast<float4*>(y)[at] = make_float4(fmaf(q.x, s, t), fmaf(q.y, s, t), fmaf(q.z, s, t), fmaf(q.w, s, t));
+        if (resid == nullptr && !relu) {
+          reinterpret_cast<float4*>(y)[at] = make_float4(fmaf(q.x, s, t), fmaf(q.y, s, t), fmaf(q.z, s, t), fmaf(q.w, s, t));
+        } else {
+          const float4 r = resid ? reinterpret_cast<const float4*>(resid)[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+          reinterpret_cast<float4*>(y)[at] = make_float4(act(fmaf(q.x, s, t), r.x), act(fmaf(q.y, s, t), r.y), act(fmaf(q.z, s, t), r.z),
+                                                         act(fmaf(q.w, s, t), r.w));
+        }
         a0 += (q.x + q.y) + (q.z + q.w);
         a1 = fmaf(q.x, q.x, a1);
         a1 = fmaf(q.y, q.y, a1);
@@ -105,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_fwd_kernel(const float* __rest
         cnt += 4;
       } else {
         const float q = x[at];
-        y[at] = fmaf(q, s, t);
+        y[at] = (resid == nullptr && !relu) ? fmaf(q, s, t) : act(fmaf(q, s, t), resid ? resid[at] : 0.f);
         a0 += q;
         a1 = fmaf(q, q, a1);
         cnt += 1;
@@ -135,11 +155,11 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
                                                              const float* __restrict__ mean_inv, float* __restrict__ gx,
                                                              float* __restrict__ gw, float* __restrict__ gb,
                                                              double* __restrict__ part, const float* __restrict__ tap_coef,
-                                                             const float* __restrict__ tap_gout, int B, int C, int HW, int S,
-                                                             int narrow) {
+                                                             const float* __restrict__ tap_gout, const float* __restrict__ ymask,
+                                                             float* __restrict__ gres, int B, int C, int HW, int S, int narrow) {
   __shared__ double lds[bh::kWavesPerBlock * 2];
   const ChannelWalk w = channel_of(C, S, narrow != 0);
-  double v[2] = {0.0, 0.0};  // sum gy, sum gy * x
+  double v[2] = {0.0, 0.0};  // sum gz, sum gz * x   (gz = gy behind the ReLU mask, = gy without one)
   if (w.active) {
     const float s = (weight ? weight[w.c] : 1.f) * inv_std[w.c];
     // DeepInversion tap (kernel D's backward riding in this launch): gx += g * (A_c + B_c * x), the term rounded exactly as
@@ -161,7 +181,13 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
       const uint32_t b = B == 1 ? 0u : u / unit, j = u - b * unit;
       const size_t at = (size_t)b * cstride + cbase + j;
       if (vec) {
-        const float4 g = reinterpret_cast<const float4*>(gy)[at], q = reinterpret_cast<const float4*>(x)[at];
+        float4 g = reinterpret_cast<const float4*>(gy)[at];
+        const float4 q = reinterpret_cast<const float4*>(x)[at];
+        if (ymask) {
+          const float4 m = reinterpret_cast<const float4*>(ymask)[at];
+          g = make_float4(m.x > 0.f ? g.x : 0.f, m.y > 0.f ? g.y : 0.f, m.z > 0.f ? g.z : 0.f, m.w > 0.f ? g.w : 0.f);
+        }
+        if (gres) reinterpret_cast<float4*>(gres)[at] = g;
         if (gx) {
           if (tap_coef)
             reinterpret_cast<float4*>(gx)[at] = make_float4(g.x * s + fmaf(tb, q.x, ta), g.y * s + fmaf(tb, q.y, ta),
@@ -176,7 +202,10 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
         a1 = fmaf(g.w, q.w, a1);
         cnt += 4;
       } else {
-        const float g = gy[at], q = x[at];
+        float g = gy[at];
+        const float q = x[at];
+        if (ymask && !(ymask[at] > 0.f)) g = 0.f;
+        if (gres) gres[at] = g;
         if (gx) gx[at] = tap_coef ? g * s + fmaf(tb, q, ta) : g * s;
         a0 += g;
         a1 = fmaf(g, q, a1);
@@ -210,11 +239,12 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
                                                                  const float* __restrict__ inv_std,
                                                                  const float* __restrict__ mean_inv, float* __restrict__ d_gy,
                                                                  float* __restrict__ d_x, float* __restrict__ d_w,
-                                                                 double* __restrict__ part, int B, int C, int HW, int S,
+                                                                 double* __restrict__ part, const float* __restrict__ ymask,
+                                                                 const float* __restrict__ ggr, int B, int C, int HW, int S,
                                                                  int narrow) {
   __shared__ double lds[bh::kWavesPerBlock];
   const ChannelWalk w = channel_of(C, S, narrow != 0);
-  double v[1] = {0.0};  // sum ggx * gy
+  double v[1] = {0.0};  // sum ggx * gz
   if (w.active) {
     const float inv = inv_std[w.c], mi = mean_inv[w.c];
     const float s = (weight ? weight[w.c] : 1.f) * inv;
@@ -231,12 +261,24 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
       const uint32_t b = B == 1 ? 0u : u / unit, j = u - b * unit;
       const size_t at = (size_t)b * cstride + cbase + j;
       if (vec) {
-        const float4 g = reinterpret_cast<const float4*>(gy)[at];
+        float4 g = reinterpret_cast<const float4*>(gy)[at];
         const float4 q = ggx ? reinterpret_cast<const float4*>(ggx)[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (ymask) {
+          const float4 yv = reinterpret_cast<const float4*>(ymask)[at];
+          m = make_float4(yv.x > 0.f ? 1.f : 0.f, yv.y > 0.f ? 1.f : 0.f, yv.z > 0.f ? 1.f : 0.f, yv.w > 0.f ? 1.f : 0.f);
+          g = make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);  // gz
+        }
         if (d_gy) {
           const float4 xv = reinterpret_cast<const float4*>(x)[at];
-          reinterpret_cast<float4*>(d_gy)[at] = make_float4(fmaf(q.x, s, fmaf(kwi, xv.x, shift)), fmaf(q.y, s, fmaf(kwi, xv.y, shift)),
-                                                            fmaf(q.z, s, fmaf(kwi, xv.z, shift)), fmaf(q.w, s, fmaf(kwi, xv.w, shift)));
+          float4 o = make_float4(fmaf(q.x, s, fmaf(kwi, xv.x, shift)), fmaf(q.y, s, fmaf(kwi, xv.y, shift)),
+                                 fmaf(q.z, s, fmaf(kwi, xv.z, shift)), fmaf(q.w, s, fmaf(kwi, xv.w, shift)));
+          if (ggr) {
+            const float4 rr = reinterpret_cast<const float4*>(ggr)[at];
+            o = make_float4(o.x + rr.x, o.y + rr.y, o.z + rr.z, o.w + rr.w);
+          }
+          if (ymask) o = make_float4(m.x > 0.f ? o.x : 0.f, m.y > 0.f ? o.y : 0.f, m.z > 0.f ? o.z : 0.f, m.w > 0.f ? o.w : 0.f);
+          reinterpret_cast<float4*>(d_gy)[at] = o;
         }
         if (d_x) reinterpret_cast<float4*>(d_x)[at] = make_float4(kwi * g.x, kwi * g.y, kwi * g.z, kwi * g.w);
         a0 = fmaf(q.x, g.x, a0);
@@ -245,9 +287,11 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
         a0 = fmaf(q.w, g.w, a0);
         cnt += 4;
       } else {
-        const float g = gy[at];
+        float g = gy[at];
         const float q = ggx ? ggx[at] : 0.f;
-        if (d_gy) d_gy[at] = fmaf(q, s, fmaf(kwi, x[at], shift));
+        const bool on = ymask == nullptr || ymask[at] > 0.f;
+        if (!on) g = 0.f;  // gz
+        if (d_gy) d_gy[at] = on ? fmaf(q, s, fmaf(kwi, x[at], shift)) + (ggr ? ggr[at] : 0.f) : 0.f;
         if (d_x) d_x[at] = kwi * g;
         a0 = fmaf(q, g, a0);
         cnt += 1;
@@ -312,31 +356,33 @@ int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW) {
 }
 
 int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* inv_std, const float* mean_inv, float* y,
-                   double* stats, int32_t B, int32_t C, int32_t HW, void* stream) {
+                   double* stats, const float* residual, int32_t relu, int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || y == nullptr) return BH_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(stats) & 7u) != 0) return BH_EINVAL;
-  if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u) != 0) return BH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(stats) & 7u) != 0 || (relu != 0 && relu != 1)) return BH_EINVAL;
+  if ((HW & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(residual)) & 15u) != 0)
+    return BH_EINVAL;
   int S = 1, narrow = 0;
   const int grid = eval_bn_grid(B, C, HW, S, narrow);
   hipLaunchKernelGGL(bn_eval_fwd_kernel, dim3(grid), dim3(kBlock), 0, bh::as_stream(stream), x, weight, bias, inv_std, mean_inv,
-                     y, stats, B, C, HW, S, narrow);
+                     y, stats, residual, relu, B, C, HW, S, narrow);
   return bh::launch_status();
 }
 
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
-                   float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, int32_t B, int32_t C,
-                   int32_t HW, void* stream) {
+                   float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, const float* y_mask,
+                   float* g_residual, int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || gy == nullptr) return BH_EINVAL;
   if ((reinterpret_cast<uintptr_t>(tap_coef) & 7u) != 0 || (tap_coef != nullptr && gx == nullptr)) return BH_EINVAL;
-  if ((HW & 3) == 0 &&
-      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx)) & 15u) != 0)
+  if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx) |
+                         reinterpret_cast<uintptr_t>(y_mask) | reinterpret_cast<uintptr_t>(g_residual)) & 15u) != 0)
     return BH_EINVAL;
   int S = 1, narrow = 0;
   const int grid = eval_bn_grid(B, C, HW, S, narrow);
   if (S > 1 && workspace == nullptr) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, gy, x, weight, inv_std, mean_inv, gx, gw, gb, workspace,
-                     tap_coef, tap_gout, B, C, HW, S, narrow);
+                     tap_coef, tap_gout, y_mask, g_residual, B, C, HW, S, narrow);
   if (S > 1 && (gw != nullptr || gb != nullptr))
     hipLaunchKernelGGL(bn_eval_combine_kernel<2>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, workspace, inv_std,
                        mean_inv, gw, gb, C, S);
@@ -345,17 +391,18 @@ int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const f
 
 int bh_bn_eval_bwd_bwd(const float* ggx, const float* ggw, const float* ggb, const float* gy, const float* x, const float* weight,
                        const float* inv_std, const float* mean_inv, float* d_gy, float* d_x, float* d_w, double* workspace,
-                       int32_t B, int32_t C, int32_t HW, void* stream) {
+                       const float* y_mask, const float* gg_residual, int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || gy == nullptr) return BH_EINVAL;
   if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(ggx) |
-                         reinterpret_cast<uintptr_t>(d_gy) | reinterpret_cast<uintptr_t>(d_x)) & 15u) != 0)
+                         reinterpret_cast<uintptr_t>(d_gy) | reinterpret_cast<uintptr_t>(d_x) | reinterpret_cast<uintptr_t>(y_mask) |
+                         reinterpret_cast<uintptr_t>(gg_residual)) & 15u) != 0)
     return BH_EINVAL;
   int S = 1, narrow = 0;
   const int grid = eval_bn_grid(B, C, HW, S, narrow);
   if (S > 1 && workspace == nullptr) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   hipLaunchKernelGGL(bn_eval_bwd_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, ggx, ggw, ggb, gy, x, weight, inv_std, mean_inv, d_gy,
-                     d_x, d_w, workspace, B, C, HW, S, narrow);
+                     d_x, d_w, workspace, y_mask, gg_residual, B, C, HW, S, narrow);
   if (S > 1 && d_w != nullptr)
     hipLaunchKernelGGL(bn_eval_combine_kernel<1>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, workspace, inv_std,
                        mean_inv, d_w, static_cast<float*>(nullptr), C, S);

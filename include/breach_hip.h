@@ -260,8 +260,10 @@ int bh_bn_bwd_accumulate(const float* x, const float* gin, int32_t hw, const bh_
 /* `stats` (may be NULL): 2 * C * S doubles receiving sum(x) and sum(x^2) per (channel, slab), S = bh_bn_eval_slabs -- the layout
  * bh_bn_finalize reads for a layer (point it at sums_dev + 2 * sums_off of that layer): the DeepInversion prior's statistics of
  * a BatchNorm input then come out of the pass that reads the input anyway, and bh_bn_sums is not needed. */
+/* Epilogue (both optional): `residual` ([B,C,HW], NULL = none) is added to the affine map and `relu` (0 / 1) clamps the result at
+ * zero -- y = relu(x * s_c + t_c + residual), the tail of a ResNet block in the BatchNorm's own launch. */
 int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const float* inv_std, const float* mean_inv, float* y,
-                   double* stats, int32_t B, int32_t C, int32_t HW, void* stream);
+                   double* stats, const float* residual, int32_t relu, int32_t B, int32_t C, int32_t HW, void* stream);
 /* Slabs S a channel is cut into for this geometry -- the rule of bh_bn_plan_build (1 below 12 288 elements per channel: the
  * whole order is then ONE launch; otherwise about one per 8 192 elements, at most 64, and the backward orders take a small
  * second launch that adds the per-slab sums in slab order).  `workspace` below: 2 * C * S doubles (may be NULL when S == 1). */
@@ -271,16 +273,19 @@ int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW);
  * and `tap_gout` (device scalar, NULL = 1): the DeepInversion prior's backward of this BatchNorm input rides in the launch --
  * gx = gy * s_c + gout * (A_c + B_c * x) -- instead of a read-modify-write pass of its own (bh_bn_bwd_accumulate): x is read
  * here anyway, so the prior's backward costs no traffic on models whose BatchNorm runs through these kernels.
- * reference: deepinversion.py:93-103 (the statistic whose gradient this is; math only). */
+ * reference: deepinversion.py:93-103 (the statistic whose gradient this is; math only).
+ * `y_mask` (may be NULL): the forward OUTPUT of a launch with relu = 1; the incoming gradient is then masked first, gz = gy * [y > 0],
+ * and gz takes gy's place everywhere (gx, gw, gb).  `g_residual` (may be NULL): receives gz, the gradient of the residual input. */
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
-                   float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, int32_t B, int32_t C,
-                   int32_t HW, void* stream);
+                   float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, const float* y_mask,
+                   float* g_residual, int32_t B, int32_t C, int32_t HW, void* stream);
 /* Derivative of bh_bn_eval_bwd for incoming (ggx [B,C,HW], ggw [C], ggb [C]; each may be NULL = zero):
  * d_gy = ggx * s_c + ggw_c * (inv_std_c * x - mean_inv_c) + ggb_c;  d_x = ggw_c * inv_std_c * gy;  d_w_c = inv_std_c * sum(ggx * gy).
- * Outputs may be NULL (not computed). */
+ * Outputs may be NULL (not computed).  With `y_mask` (the same forward output given to bh_bn_eval_bwd) and `gg_residual` (incoming
+ * gradient of g_residual, may be NULL): d_gy = [y > 0] * (... + gg_residual), and gy is replaced by gz = gy * [y > 0] in d_x / d_w. */
 int bh_bn_eval_bwd_bwd(const float* ggx, const float* ggw, const float* ggb, const float* gy, const float* x, const float* weight,
                        const float* inv_std, const float* mean_inv, float* d_gy, float* d_x, float* d_w, double* workspace,
-                       int32_t B, int32_t C, int32_t HW, void* stream);
+                       const float* y_mask, const float* gg_residual, int32_t B, int32_t C, int32_t HW, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * LayerNorm over the last dimension (elementwise affine) of the attacker's private model copy, one or two launches per

@@ -610,6 +610,119 @@ def test_eval_batchnorm_function_matches_torch_through_two_orders(shape, affine,
         close(got[2][1], ref[2][1], "second order wrt weight")
 
 
+@pytest.mark.parametrize("relu,with_residual", [(True, False), (True, True), (False, True)])
+@pytest.mark.parametrize("shape", [(1, 64, 56, 56), (2, 12, 7, 7), (3, 5, 9, 11), (8, 16, 64, 64), (1, 512, 7, 7)])
+def test_eval_batchnorm_epilogue_matches_torch_through_two_orders(shape, relu, with_residual, hip_lib):
+    """Kernel E with its epilogue -- y = relu(x * s + t + residual) in the BatchNorm's launch, the ReLU mask and the residual's
+    gradient in both backward orders -- against `F.relu(F.batch_norm(x, ...) + residual)` in fp64 on the CPU (the arithmetic
+    the reference's model runs) through the two autograd orders the attack uses: y; d/d(x, residual, weight, bias) of a scalar
+    of y under create_graph; and the gradient of a scalar of THOSE with respect to x, residual, weight AND bias.  Wide, narrow,
+    scalar and slab-split geometries.  Pre-activations are kept 1e-3 away from the ReLU kink so that fp32 and fp64 agree on
+    the mask."""
+    import copy
+
+    from breaching_amd.attacker import _launch_eval_bn, use_affine_eval_batchnorm
+
+    torch.manual_seed(sum(shape) + 7 * relu + 3 * with_residual)
+    C = shape[1]
+    bn = torch.nn.BatchNorm2d(C).eval()
+    with torch.no_grad():
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.4, 2.0)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.2)
+    x_cpu = torch.randn(shape, dtype=torch.float64)
+    r_cpu = torch.randn(shape, dtype=torch.float64) if with_residual else None
+    with torch.no_grad():  # move pre-activations off the kink
+        s = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps)).view(1, -1, 1, 1)
+        z = torch.nn.functional.batch_norm(x_cpu, bn.running_mean.double(), bn.running_var.double(), bn.weight.double(), bn.bias.double(),
+                                           False, 0.0, bn.eps) + (r_cpu if with_residual else 0)
+        near = z.abs() < 1e-3
+        x_cpu = x_cpu + torch.where(near, (torch.where(z >= 0, 2e-3, -2e-3) - z) / s, torch.zeros_like(z))
+        x_cpu = x_cpu.float().double()  # both sides see exactly the fp32 values
+        if with_residual:
+            r_cpu = r_cpu.float().double()
+    mixes = [torch.randn(shape, dtype=torch.float64) for _ in range(3)]
+    mw, mb = torch.randn(C, dtype=torch.float64), torch.randn(C, dtype=torch.float64)
+
+    def run(forward, x, r, params, cast):
+        x = x.clone().requires_grad_(True)
+        inputs = [x] + ([r.clone().requires_grad_(True)] if r is not None else [])
+        y = forward(*inputs)
+        first = torch.autograd.grad((y * y * cast(mixes[0])).sum(), [*inputs, *params], create_graph=True)
+        scalar = (first[0] * cast(mixes[1])).sum() + (first[-2] * cast(mw)).sum() + (first[-1] * cast(mb)).sum()
+        if r is not None:
+            scalar = scalar + (first[1] * cast(mixes[2])).sum()
+        second = torch.autograd.grad(scalar, [*inputs, *params], allow_unused=True)
+        return y.detach(), [f.detach() for f in first], [None if g is None else g.detach() for g in second]
+
+    ref_bn = copy.deepcopy(bn).double()
+
+    def ref_forward(x, r=None):
+        z = ref_bn(x) if r is None else ref_bn(x) + r
+        return torch.relu(z) if relu else z
+
+    ref = run(ref_forward, x_cpu, r_cpu, list(ref_bn.parameters()), lambda t: t)
+    hip_bn = use_affine_eval_batchnorm(copy.deepcopy(bn).to(_dev()), "hip")
+    to_dev = lambda t: t.to(_dev(), torch.float32)  # noqa: E731
+    got = run(lambda x, r=None: _launch_eval_bn(hip_bn, x, None, None, r, relu), to_dev(x_cpu), None if r_cpu is None else to_dev(r_cpu),
+              list(hip_bn.parameters()), to_dev)
+
+    def close(a, b, what):
+        a, b = a.cpu().double().numpy(), b.numpy()
+        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+        assert err <= 3e-5, (what, err)
+
+    names = ["x"] + (["residual"] if with_residual else []) + ["weight", "bias"]
+    close(got[0], ref[0], "y")
+    for k, name in enumerate(names):
+        close(got[1][k], ref[1][k], f"first order wrt {name}")
+        assert (got[2][k] is None) == (ref[2][k] is None), name
+        if ref[2][k] is not None:
+            close(got[2][k], ref[2][k], f"second order wrt {name}")
+
+
+def test_resnet_blocks_run_fused_and_match_the_stock_modules():
+    """The ResNet-18 / ResNet-50 copies the attacker builds run their BatchNorm -> (+ identity) -> ReLU tails inside kernel E's
+    launches (`_PendingBatchNorm`): logits, the parameter gradient under create_graph and the gradient of a scalar of it with
+    respect to the input agree with the same model on stock torch modules (fp32 on the GPU both; a few pre-activations sit on
+    the kink, so the comparison is on norms), and the launch count of the fused model is what the block structure predicts."""
+    import copy
+
+    import breaching_amd.attacker as A
+    from breaching_amd.cases import build_model
+
+    for name, n_fused_relu, n_plain in (("resnet18", 17, 3), ("resnet50", 49, 4)):
+        torch.manual_seed(0)
+        stock = build_model(name, 1000, 0).to(_dev()).eval()
+        fused = A.use_affine_eval_batchnorm(copy.deepcopy(stock), "hip")
+        calls = []
+        inner = A._launch_eval_bn
+
+        def spy(module, x, sink, tap, residual, relu):
+            calls.append((residual is not None, bool(relu)))
+            return inner(module, x, sink, tap, residual, relu)
+
+        A._launch_eval_bn = spy
+        try:
+            x = torch.randn(2, 3, 224, 224, device=_dev())
+            out = {}
+            for tag, model in (("stock", stock), ("fused", fused)):
+                xq = x.clone().requires_grad_(True)
+                logits = model(xq)
+                grads = torch.autograd.grad(logits.logsumexp(1).sum(), list(model.parameters()), create_graph=True)
+                (gx,) = torch.autograd.grad(sum((g * g).sum() for g in grads), xq)
+                out[tag] = (logits.detach(), torch.cat([g.detach().flatten() for g in grads]), gx)
+        finally:
+            A._launch_eval_bn = inner
+        assert sum(1 for r, relu in calls if relu) == n_fused_relu and sum(1 for r, relu in calls if not relu) == n_plain, calls
+        assert sum(1 for r, relu in calls if r and relu) == (8 if name == "resnet18" else 16)  # one residual tail per block
+        for k, what in enumerate(("logits", "parameter gradient", "second-order input gradient")):
+            a, b = out["fused"][k].double(), out["stock"][k].double()
+            rel = float((a - b).norm() / b.norm())
+            assert rel <= (1e-5 if k == 0 else 2e-3), (name, what, rel)
+
+
 def test_deepinversion_statistics_come_from_the_batchnorm_forward_kernel(kernels_oracle, hip_lib, monkeypatch):
     """With the eval-mode BatchNorm layers on kernel E, the DeepInversion prior needs no pass of its own over the activations:
     from the second evaluation on (the first one learns the shapes and builds the plan) every layer's forward kernel writes
@@ -790,7 +903,7 @@ def test_bn_eval_bwd_tap_arguments_against_numpy(hip_lib):
             ws = torch.empty(2 * C * S, dtype=torch.float64, device=_dev())
             _lib.check(hip_lib.bh_bn_eval_bwd(_lib.ptr(t["gy"]), _lib.ptr(t["x"]), _lib.ptr(t["w"]), _lib.ptr(t["inv"]), _lib.ptr(t["mi"]),
                                               _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), _lib.ptr(t["coef"] if tap else None),
-                                              _lib.ptr(g if tap else None), B, C, HW, _lib.current_stream_handle(_dev())), "bwd")
+                                              _lib.ptr(g if tap else None), None, None, B, C, HW, _lib.current_stream_handle(_dev())), "bwd")
             out[tap] = [v.cpu().numpy().astype(np.float64) for v in (gx, gw, gb)]
         s = (w.astype(np.float64) * inv)[None, :, None, None]
         plain = host["gy"].astype(np.float64) * s

@@ -88,3 +88,53 @@ def test_restarts_in_flight_keep_their_rate_after_an_earlier_attack_in_the_same_
     rate_alone, rate_after = alone["passes"][1]["it_per_s"], after["passes"][1]["it_per_s"]
     print(f"  4 restarts in flight: {rate_alone} it/s alone, {rate_after} it/s after an earlier attack in the process")
     assert rate_after >= 0.75 * rate_alone
+
+
+def test_side_streams_are_chosen_on_different_hardware_pipes():
+    """Trials in flight need streams that do not share one of the four hardware compute pipes (two busy streams on one pipe
+    run slower than one after the other: profiles/r4_inflight_pipes_probe.jsonl).  Fresh processes: (a) whatever streams the
+    process created and used before, `side_streams` returns four streams that are pairwise collision-free by its own
+    measurement, caches the choice and hands the same streams to the next group; (b) fed the 1st, 5th, 2nd, 6th, 3rd, 7th, 4th
+    stream of the process in that order -- every second candidate on the pipe of its predecessor -- the measurement finds
+    exactly those three collisions and keeps streams 1, 2, 3, 4."""
+    code = r"""
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+from breaching_amd import streams
+dev = torch.device("cuda", 0)
+mode, decoys = sys.argv[1], int(sys.argv[2])
+pool = [torch.cuda.Stream(dev) for _ in range(8 if mode == "scrambled" else decoys)]
+for s in pool:
+    with torch.cuda.stream(s):
+        torch.zeros(1, device=dev).add_(1)
+torch.cuda.synchronize()
+if mode == "scrambled":
+    order = [pool[i] for i in (0, 4, 1, 5, 2, 6, 3, 7)]
+    chosen, report = streams.calibrate(dev, 4, candidates=order)
+    picked = [pool.index(s) for s in chosen]
+    again = chosen[:3]
+else:
+    chosen = streams.side_streams(dev, 4)
+    report, picked = streams.calibration_report(dev), None
+    again = streams.side_streams(dev, 3)
+(ga, _), (gb, _) = streams._probe_graphs(dev, chosen[0])
+solo = min(streams._timed(dev, [(chosen[0], ga)]) for _ in range(3))
+pairs = {}
+for i in range(4):
+    for j in range(i + 1, 4):
+        pairs[f"{i}-{j}"] = min(streams._timed(dev, [(chosen[i], ga), (chosen[j], gb)]) for _ in range(2))
+print(json.dumps(dict(report=report, solo_ms=solo, pairs=pairs, distinct=len({s.cuda_stream for s in chosen}), picked=picked,
+                      cached=[a.cuda_stream == b.cuda_stream for a, b in zip(again, chosen)])))
+"""
+    for mode, decoys in (("plain", 0), ("plain", 1), ("plain", 3), ("scrambled", 0)):
+        proc = subprocess.run([sys.executable, "-c", code, mode, str(decoys)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert proc.returncode == 0, proc.stderr[-2000:]
+        rec = json.loads(proc.stdout.strip().splitlines()[-1])
+        print(f"  {mode}, {decoys} earlier streams: candidates {rec['report']['candidates']}, collisions skipped {rec['report']['collisions']}, "
+              f"solo {rec['solo_ms']:.3f} ms, worst pair {max(rec['pairs'].values()):.3f} ms, picked {rec['picked']}")
+        assert rec["distinct"] == 4 and rec["cached"] == [True, True, True] and not rec["report"].get("incomplete")
+        assert max(rec["pairs"].values()) <= 3.0 * rec["solo_ms"], rec  # no two of the chosen streams collide
+        if mode == "scrambled":
+            assert rec["picked"] == [0, 1, 2, 3]
+            assert [(c["candidate"], c["with_chosen"]) for c in rec["report"]["collisions"]] == [(2, 0), (4, 1), (6, 2)]

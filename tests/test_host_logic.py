@@ -494,3 +494,97 @@ def test_model_copy_modules_are_swapped_in_place():
     model.eval(), reference.eval()
     per_sample = lambda m: torch.func.vmap(torch.func.grad(lambda v: (m(v[None]) ** 2).sum()))(x)  # noqa: E731
     torch.testing.assert_close(per_sample(model), per_sample(reference), rtol=1e-3, atol=1e-4)
+
+
+def test_pending_batchnorm_absorbs_residual_and_relu_without_changing_the_model(monkeypatch):
+    """`_PendingBatchNorm`: the eval-BatchNorm output waits for its first consumer so that `+ identity` and `relu` ride in the
+    BatchNorm's launch.  The peephole logic is host code: here the kernel launch is replaced by its torch formula (and the
+    modules are told they run on the GPU), and ResNet-style blocks written in every common way -- `out += identity` then an
+    in-place ReLU module, `torch.relu(out + identity)`, `out.add_(identity); self.relu(out)` without rebinding, `identity + out`
+    then `.relu()`, and a BatchNorm output that is used twice by non-ReLU consumers -- give the values and input gradients of
+    the stock modules, with exactly the launches expected (fused where the pattern is there, plain otherwise, none for a
+    BatchNorm output nobody uses)."""
+    import copy
+
+    import breaching_amd.attacker as A
+
+    calls = []
+
+    def fake_launch(module, x, sink, tap, residual, relu):
+        calls.append((residual is not None, bool(relu)))
+        inv_std, mean_inv = module._frozen_statistics()
+        z = x * (module.weight * inv_std).view(1, -1, 1, 1) + (module.bias - module.weight * mean_inv).view(1, -1, 1, 1)
+        if residual is not None:
+            z = z + residual
+        return torch.relu(z) if relu else z
+
+    monkeypatch.setattr(A, "_launch_eval_bn", fake_launch)
+    monkeypatch.delenv("BREACH_HIP_FUSE_BN_RELU", raising=False)
+
+    class Block(torch.nn.Module):
+        def __init__(self, inplace, style):
+            super().__init__()
+            self.c1, self.b1 = torch.nn.Conv2d(4, 4, 3, padding=1), torch.nn.BatchNorm2d(4)
+            self.c2, self.b2 = torch.nn.Conv2d(4, 4, 3, padding=1), torch.nn.BatchNorm2d(4)
+            self.relu = torch.nn.ReLU(inplace=inplace)
+            self.down = torch.nn.Sequential(torch.nn.Conv2d(4, 4, 1), torch.nn.BatchNorm2d(4))
+            self.style = style
+
+        def forward(self, x):
+            identity = self.down(x)
+            out = self.relu(self.b1(self.c1(x)))
+            out = self.b2(self.c2(out))
+            if self.style == 0:
+                out += identity
+                out = self.relu(out)
+            elif self.style == 1:
+                out = torch.relu(out + identity)
+            elif self.style == 2:
+                out.add_(identity)
+                self.relu(out)  # in-place module, result not rebound
+            elif self.style == 3:
+                out = identity + out
+                out = out.relu()
+            else:  # used twice, never through a ReLU first: the plain values must survive; `identity` is never consumed
+                out = torch.tanh(out) + torch.relu(out) + out.shape[1]
+            return out
+
+    fused = [(False, True), (False, False), (True, True)]  # bn1 + relu; downsample bn (plain, it becomes the residual); bn2 + identity + relu
+    expected = {0: fused, 1: fused, 2: fused, 3: fused, 4: [(False, True), (False, False)]}
+    for style in range(5):
+        for inplace in (True, False):
+            if style == 2 and not inplace:
+                continue
+            torch.manual_seed(style)
+            ref = Block(inplace, style).eval()
+            for m in ref.modules():
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_()
+                    m.running_var.uniform_(0.5, 2)
+                    m.weight.data.normal_(1, 0.2)
+                    m.bias.data.normal_()
+            hip = A.use_affine_eval_batchnorm(copy.deepcopy(ref), "hip")
+            for m in hip.modules():
+                if isinstance(m, A._EvalAffineBatchNorm2d):
+                    m._runs_on_hip = lambda x: True  # the launch itself is the torch formula above
+            x = torch.randn(2, 4, 8, 8)
+            calls.clear()
+            y_hip = hip(x.clone())
+            assert calls == expected[style], (style, inplace, calls)
+            if style != 2:
+                assert type(y_hip) is torch.Tensor
+            torch.testing.assert_close(y_hip + 0, ref(x), rtol=1e-5, atol=1e-5)
+            xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            (ga,) = torch.autograd.grad((hip(xa) ** 2).sum(), xa)
+            (gb,) = torch.autograd.grad((ref(xb) ** 2).sum(), xb)
+            torch.testing.assert_close(ga, gb, rtol=1e-4, atol=1e-5)
+    # switched off: the modules launch immediately, nothing is deferred
+    monkeypatch.setenv("BREACH_HIP_FUSE_BN_RELU", "0")
+    calls.clear()
+    hip(x)
+    assert calls == [(False, False)] * 3
+    monkeypatch.delenv("BREACH_HIP_FUSE_BN_RELU")
+    A.use_affine_eval_batchnorm(hip, "hip", fuse_epilogue=False)
+    calls.clear()
+    hip(x)
+    assert calls == [(False, False)] * 3
