@@ -138,7 +138,7 @@ def parse_args():
     p.add_argument("--cpu-baseline-iters", type=int, default=80,
                    help="timed CPU iterations of the reference (or its port), ~10 s of host work (0 disables)")
     p.add_argument("--cpu-threads", type=int, default=0,
-                   help="threads of the CPU baseline (0 = min(os.cpu_count(), 32): the measured optimum, profiles/r4_cpu_thread_sweep.json)")
+                   help="threads of the CPU baseline (0 = min(os.cpu_count(), 16): the measured optimum, profiles/r4_cpu_thread_sweep.json)")
     p.add_argument("--no-hbm-resident", action="store_true", help="skip the BERT-base sized kernel-A timing (roofline.hbm_resident)")
     p.add_argument("--model", default="resnet18")
     p.add_argument("--no-kernel-timing", action="store_true")
@@ -412,9 +412,10 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
         host_cores = os.cpu_count() or 1
-        # torch's CPU convolutions stop scaling well before 32 threads on this B = 1 workload and lose beyond it (measured on the
-        # 256-logical-core host of the GPU box: profiles/r4_cpu_thread_sweep.json); --cpu-threads overrides
-        threads = args.cpu_threads if args.cpu_threads > 0 else min(host_cores, 32)
+        # torch's CPU convolutions at B = 1 peak at 16 threads on the 256-logical-core host of the GPU box and LOSE beyond it
+        # (profiles/r4_cpu_thread_sweep.json: 8 / 16 / 32 / 64 / 128 threads = 15.7 / 18.3 / 8.3 / 3.3 / 0.9 it/s): the baseline is
+        # timed at its best thread count, not at os.cpu_count(); --cpu-threads overrides
+        threads = args.cpu_threads if args.cpu_threads > 0 else min(host_cores, 16)
         torch.set_num_threads(threads)
         cpu_case = build_case(args.model, "ImageNet", 1, device="cpu")
         x0_cpu = initial_candidate(cpu_case.data_cfg, 1)

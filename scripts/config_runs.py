@@ -13,6 +13,10 @@ parser.add_argument("--full", action="store_true")
 parser.add_argument("--only", default=None)
 parser.add_argument("--its", type=int, default=200, help="iterations of the short configurations (configs[2], configs[4])")
 parser.add_argument("--per-process", action="store_true", help="one process per configuration instead of one process for all")
+parser.add_argument("--starts", type=int, default=0,
+                    help="--only 24k: this many full-length (24 000-iteration) ResNet-18 runs of configs[1] from the reference's starting points "
+                         "(nominal x0, then starts <= 16 ulp away, seeded like oracle/make_golden.py), four in flight, compared with the "
+                         "reference's own full-length runs in tests/golden/attack_resnet18_24k.npz")
 args = parser.parse_args()
 if args.only is None and args.per_process:
     import subprocess
@@ -51,6 +55,48 @@ def run(name, case, cfg, x0=None):
     print(name, json.dumps(entry), flush=True)
 
 
+if args.only == "24k":
+    import numpy as np
+    from breaching_amd.cases import ulp_perturb
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "attack_resnet18_24k.npz"))
+    its, n = int(gold["iterations"]), max(args.starts, 1)
+    case = build_case("resnet18", "ImageNet", 1, device=dev)  # gradient on the CPU: the target the reference attacked
+    starts = {}
+    for idx in range(n):
+        x0 = initial_candidate(case.data_cfg, 1)
+        starts[idx] = x0 if idx == 0 else ulp_perturb(x0, 16, torch.Generator().manual_seed(int(gold["twin_seed"]) + idx))
+    cfg = breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={its}", "optim.callback=4000", f"restarts.num_trials={n}"])
+    attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
+    attacker._preset = dict(inits={t: (x,) for t, x in starts.items()}, labels=None)  # every trial from its prescribed start
+    scored, inner = [], attacker._score_trial
+
+    def spy(candidate, labels, rec_model, shared_data):
+        score = inner(candidate, labels, rec_model, shared_data)
+        scored.append((psnr(candidate, case.true_user_data["data"], case.data_cfg), float(score)))
+        return score
+
+    attacker._score_trial = spy
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {})
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    marks = [999, 8997, 9100, 14999, 15100, 21014, 21100, its - 1]
+    ref_hist = np.concatenate([gold["history"][None, :], gold["twin_history"]], axis=0).astype(np.float64)
+    report = dict(starts=n, iterations_each=its, wall_s=round(dt, 1), trial_iterations_per_s=round(n * its / dt, 1),
+                  execution=sorted(set(stats["execution"]["trials"].values())),
+                  hip={f"loss@{m}": [round(stats[f"Trial_{t}_Val"][m], 6) for t in range(n)] for m in marks},
+                  reference={f"loss@{m}": [round(float(v), 6) for v in ref_hist[:, m]] for m in marks})
+    report["hip"].update(opt_value=[round(s, 6) for _, s in scored], psnr_db=[round(p, 4) for p, _ in scored])
+    report["reference"].update(opt_value=[round(float(v), 6) for v in np.concatenate([[gold["opt_value"]], gold["twin_opt_value"]])],
+                               psnr_db=[round(float(v), 4) for v in np.concatenate([[gold["psnr"]], gold["twin_psnr"]])])
+    for key in ("opt_value", "psnr_db", f"loss@{its - 1}"):
+        h, r = np.asarray(report["hip"][key]), np.asarray(report["reference"][key])
+        print(f"  {key:12s} hip {h.mean():.6f} +- {h.std(ddof=1) if len(h) > 1 else 0:.6f} [{h.min():.6f}, {h.max():.6f}]   "
+              f"reference {r.mean():.6f} +- {r.std(ddof=1):.6f} [{r.min():.6f}, {r.max():.6f}]", flush=True)
+    print(json.dumps(report), flush=True)
+    raise SystemExit(0)
 if args.only in (None, "1"):
     case = build_case("convnet", "CIFAR10", 1, device=dev)
     run("configs[0] ConvNet CIFAR-10 invertinggradients, 100 its", case,

@@ -30,6 +30,9 @@ for threads in [int(t) for t in args.threads.split(",")]:
     restate.run_attack(case.model, case.loss_fn, cfg, case.server_payload, case.shared_data, initial_data=x0, max_iterations=args.iters, timing=timing)
     out["iterations_per_s"][str(threads)] = round(args.iters / timing[0], 3)
     print(f"  {threads} threads: {out['iterations_per_s'][str(threads)]} it/s", file=sys.stderr, flush=True)
+    if out["iterations_per_s"][str(threads)] < 0.1 * max(out["iterations_per_s"].values()):
+        out["stopped_after"] = threads  # more threads only get slower (oversubscribed tiny convolutions): not worth minutes of box time
+        break
 best = max(out["iterations_per_s"], key=lambda k: out["iterations_per_s"][k])
 out["best_threads"] = int(best)
 print(json.dumps(out, indent=1))

@@ -684,9 +684,10 @@ def test_eval_batchnorm_epilogue_matches_torch_through_two_orders(shape, relu, w
 
 def test_resnet_blocks_run_fused_and_match_the_stock_modules():
     """The ResNet-18 / ResNet-50 copies the attacker builds run their BatchNorm -> (+ identity) -> ReLU tails inside kernel E's
-    launches (`_PendingBatchNorm`): logits, the parameter gradient under create_graph and the gradient of a scalar of it with
-    respect to the input agree with the same model on stock torch modules (fp32 on the GPU both; a few pre-activations sit on
-    the kink, so the comparison is on norms), and the launch count of the fused model is what the block structure predicts."""
+    launches (`_PendingBatchNorm`): the launch count is what the block structure predicts, and logits, the parameter gradient
+    under create_graph and the gradient of a scalar of it with respect to the input are AS CLOSE to the same model in fp64 on
+    the CPU as the stock fp32 torch modules on the GPU are (a few pre-activations sit on ReLU kinks, where any two fp32
+    evaluations differ; the fp64 run is the referee)."""
     import copy
 
     import breaching_amd.attacker as A
@@ -694,8 +695,10 @@ def test_resnet_blocks_run_fused_and_match_the_stock_modules():
 
     for name, n_fused_relu, n_plain in (("resnet18", 17, 3), ("resnet50", 49, 4)):
         torch.manual_seed(0)
-        stock = build_model(name, 1000, 0).to(_dev()).eval()
-        fused = A.use_affine_eval_batchnorm(copy.deepcopy(stock), "hip")
+        base = build_model(name, 1000, 0).eval()
+        stock = copy.deepcopy(base).to(_dev())
+        fused = A.use_affine_eval_batchnorm(copy.deepcopy(base).to(_dev()), "hip")
+        exact = copy.deepcopy(base).double()
         calls = []
         inner = A._launch_eval_bn
 
@@ -703,24 +706,28 @@ def test_resnet_blocks_run_fused_and_match_the_stock_modules():
             calls.append((residual is not None, bool(relu)))
             return inner(module, x, sink, tap, residual, relu)
 
+        x = torch.randn(2, 3, 128, 128)
+
+        def evaluate(model, xin):
+            xq = xin.clone().requires_grad_(True)
+            logits = model(xq)
+            grads = torch.autograd.grad(logits.logsumexp(1).sum(), list(model.parameters()), create_graph=True)
+            (gx,) = torch.autograd.grad(sum((g * g).sum() for g in grads), xq)
+            return [t.detach().double().cpu() for t in (logits, torch.cat([g.flatten() for g in grads]), gx)]
+
         A._launch_eval_bn = spy
         try:
-            x = torch.randn(2, 3, 224, 224, device=_dev())
-            out = {}
-            for tag, model in (("stock", stock), ("fused", fused)):
-                xq = x.clone().requires_grad_(True)
-                logits = model(xq)
-                grads = torch.autograd.grad(logits.logsumexp(1).sum(), list(model.parameters()), create_graph=True)
-                (gx,) = torch.autograd.grad(sum((g * g).sum() for g in grads), xq)
-                out[tag] = (logits.detach(), torch.cat([g.detach().flatten() for g in grads]), gx)
+            got = evaluate(fused, x.to(_dev()))
         finally:
             A._launch_eval_bn = inner
         assert sum(1 for r, relu in calls if relu) == n_fused_relu and sum(1 for r, relu in calls if not relu) == n_plain, calls
         assert sum(1 for r, relu in calls if r and relu) == (8 if name == "resnet18" else 16)  # one residual tail per block
+        plain, want = evaluate(stock, x.to(_dev())), evaluate(exact, x.double())
         for k, what in enumerate(("logits", "parameter gradient", "second-order input gradient")):
-            a, b = out["fused"][k].double(), out["stock"][k].double()
-            rel = float((a - b).norm() / b.norm())
-            assert rel <= (1e-5 if k == 0 else 2e-3), (name, what, rel)
+            err_fused = float((got[k] - want[k]).norm() / want[k].norm())
+            err_stock = float((plain[k] - want[k]).norm() / want[k].norm())
+            print(f"  {name:9s} {what:28s} relative error vs fp64: fused {err_fused:.2e}, stock torch modules {err_stock:.2e}")
+            assert err_fused <= max(2.0 * err_stock, 1e-5), (name, what, err_fused, err_stock)
 
 
 def test_deepinversion_statistics_come_from_the_batchnorm_forward_kernel(kernels_oracle, hip_lib, monkeypatch):
