@@ -1045,6 +1045,8 @@ class _PendingBatchNorm(torch.Tensor):
         self = torch.Tensor._make_wrapper_subclass(cls, x.shape, dtype=x.dtype, device=x.device, requires_grad=False)
         self._module, self._x, self._sink, self._tap = module, x, sink, tap
         self._residual, self._value = None, None
+        if tap is not None:
+            tap.pending = self  # the DeepInversion prior launches whatever is still waiting when it is evaluated
         return self
 
     def launch(self, relu=False):

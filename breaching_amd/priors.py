@@ -369,6 +369,7 @@ class _BnInputTap:
         self.module, self.record, self.layer = module, record, layer
         self.owner, self.model_idx = owner, model_idx
         self.in_producer = False  # this pass: the module's own autograd node (kernel E) carries the token, no `_BnTap` node
+        self.pending = None       # a not-yet-launched kernel E forward of this pass that will deliver the token (attacker._PendingBatchNorm)
         self.fed = False   # this pass: the module's own forward kernel writes the layer's channel sums (no bn_sums needed)
         self.x = None      # the activation of the latest forward pass (detached view, what kernel D reads)
         self.token = None  # its token (carries the autograd edge back to the tap)
@@ -394,6 +395,7 @@ class _BnInputTap:
         accepts = getattr(module, "accepts_stats_sink", None)
         on_kernel_e = self.owner is not None and callable(accepts) and accepts(x)
         self.fed = self.in_producer = False
+        self.pending = None
         if on_kernel_e and accumulate_in_kernel() and fused_tap_enabled():
             # The module's forward IS one of our autograd nodes: it emits the token itself and its backward launch
             # (bh_bn_eval_bwd, which reads x anyway) adds the prior's term -- no identity node, no launch of its own.
@@ -451,7 +453,7 @@ class HipDeepInversion(torch.nn.Module):
         """Drop the activations of the last forward pass (they hold that pass's autograd graph)."""
         for hooks in self.losses:
             for hook in hooks:
-                hook.x = hook.token = hook.live = None
+                hook.x = hook.token = hook.live = hook.pending = None
         # the taps of a pass keep their own reference to that pass's record: a retained graph stays backpropagatable
         self._records = [_BnTapRecord() for _ in getattr(self, "_records", [])]
 
@@ -496,6 +498,9 @@ class HipDeepInversion(torch.nn.Module):
         for idx, hooks in enumerate(self.losses):
             if len(hooks) == 0:
                 continue
+            for hook in hooks:  # a BatchNorm whose output nobody has consumed yet (the model's last layer): launch it now
+                if hook.token is None and hook.pending is not None:
+                    hook.pending.value()
             xs = [hook.x for hook in hooks]
             if any(x is None for x in xs) or (accumulate_in_kernel() and any(hook.token is None for hook in hooks)):
                 raise RuntimeError("DeepInversion prior evaluated before a forward pass of the attacked model.")

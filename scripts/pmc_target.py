@@ -3,6 +3,8 @@ synthetic gradient list of one BASELINE size, and kernel D on the 53 BatchNorm i
 launches each, nothing else on the GPU -- the full bench under --pmc WRITE_SIZE died inside rocprofv3 twice in round 2.
 
     rocprofv3 --pmc WRITE_SIZE -- python scripts/pmc_target.py --size resnet18|resnet50|bert|bn [--reps 6]
+    ... --size bneval_plain | bneval_tap : kernel E's backward launch over the same 53 activations without / with the DeepInversion
+        term riding in it (round 4): same FETCH_SIZE / WRITE_SIZE = the prior's backward costs no traffic of its own
 """
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +20,31 @@ args = p.parse_args()
 dev = torch.device("cuda:0")
 lib = _lib.load()
 gen = torch.Generator().manual_seed(0)
-if args.size == "bn":
+if args.size.startswith("bneval"):
+    acts = []
+    model = ResNet(50, 1000).to(dev).eval()
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    hooks = [m.register_forward_hook(lambda m, i, o: acts.append(i[0].detach().contiguous())) for m in bns]
+    with torch.no_grad():
+        model(torch.randn(8, 3, 224, 224, device=dev))
+    st = _lib.current_stream_handle(dev)
+    tap = args.size.endswith("tap")
+    gout = torch.ones(1, device=dev)
+    work = []
+    for a, m in zip(acts, bns):
+        B, C, hw = a.shape[0], a.shape[1], a.shape[2] * a.shape[3]
+        S = lib.bh_bn_eval_slabs(B, C, hw)
+        work.append((a, torch.randn_like(a), torch.empty_like(a), torch.empty(C, device=dev), torch.empty(C, device=dev),
+                     torch.empty(2 * C * S, dtype=torch.float64, device=dev), torch.randn(2 * C, device=dev),
+                     torch.rsqrt(m.running_var + m.eps).contiguous(), (m.running_mean * torch.rsqrt(m.running_var + m.eps)).contiguous(), m, B, C, hw))
+    for _ in range(args.reps):
+        for a, gy, gx, gw, gb, ws, coef, inv, mi, m, B, C, hw in work:
+            _lib.check(lib.bh_bn_eval_bwd(_lib.ptr(gy), _lib.ptr(a), _lib.ptr(m.weight), _lib.ptr(inv), _lib.ptr(mi), _lib.ptr(gx), _lib.ptr(gw),
+                                          _lib.ptr(gb), _lib.ptr(ws), _lib.ptr(coef if tap else None), _lib.ptr(gout if tap else None), None, None,
+                                          B, C, hw, st), "bn_eval_bwd")
+    torch.cuda.synchronize()
+    print(args.size, sum(a.numel() for a in acts), "elements per pass over the 53 BatchNorm inputs of ResNet-50 at B = 8")
+elif args.size == "bn":
     from breaching_amd.priors import BnStatPlan
 
     acts = []
