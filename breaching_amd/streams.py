@@ -11,7 +11,7 @@ is why `MAX_TRIALS_IN_FLIGHT` is 4: a fifth busy stream necessarily shares a pip
 Which pipe a stream lands on depends on every stream the process created before it, so taking "the next four streams of
 torch's pool" is only right by luck.  `side_streams(device, n)` therefore picks its streams by MEASUREMENT, once per process
 and device: candidates are probed pairwise with two tiny captured graphs (64 dependent one-element kernels each, replayed
-concurrently; a colliding pair takes ~10x the time of a clean one), and the first `n` candidates that collide with none of
+concurrently; a clean pair takes ~1.2x the time of one graph alone, a colliding pair ~3.1x), and the first `n` candidates that collide with none of
 the others are kept and reused by every later group of trials.  Cost: a few milliseconds, outside any timed loop.
 
 reference: none (the reference runs its restarts one after the other, optimization_based_attack.py:70-78).
@@ -27,7 +27,7 @@ log = logging.getLogger(__name__)
 PIPES = 4                 # concurrently busy streams that can each have a compute pipe to themselves
 _CANDIDATES = 12          # streams looked at before giving up on finding PIPES clean ones
 _CHAIN, _REPLAYS = 64, 6  # probe graph: dependent one-element kernels per replay, replays per measurement
-_COLLISION_FACTOR = 3.0   # pair time / solo time above which two streams are taken to share a pipe (measured: ~1.1 vs ~10)
+_COLLISION_FACTOR = 1.9   # pair time / solo time above which two streams are taken to share a pipe (measured: 1.2 clean, 3.1 colliding)
 
 _CHOSEN = {}              # device index -> (list of streams, report dict)
 

@@ -69,12 +69,21 @@ def assert_same_attack(run_a, run_b, stats_keys=None, control=None):
     RUN_VS_RUN limits below apply (and the test says so)."""
     import numpy as np
 
+    pixel_fraction = RUN_VS_RUN["pixel_fraction"]
     if control is not None:
         if runs_identical(control, run_b):
             assert runs_identical(run_a, run_b), "the control run reproduced bit for bit, the run under test did not"
             return
-        print("  [run-vs-run] the control run of the same configuration was NOT bit-identical on this box: vendor-kernel wobble; "
-              "comparing within RUN_VS_RUN limits")
+        # The box does not reproduce the baseline itself (ulp-level nondeterminism of vendor kernels; pixels whose gradient is
+        # near zero then follow rounding through Adam's normalisation while the losses stay put).  The control's own agreement
+        # with the baseline is the yardstick for the pixels; losses and opt_value keep the RUN_VS_RUN limits.
+        import numpy as np
+
+        ctl, base = control[0].detach().cpu().numpy(), run_b[0].detach().cpu().numpy()
+        ctl_close = float(np.isclose(ctl, base, rtol=RUN_VS_RUN["pixel_tol"], atol=RUN_VS_RUN["pixel_tol"]).mean())
+        pixel_fraction = min(pixel_fraction, ctl_close - 0.03)
+        print(f"  [run-vs-run] the control run of the same configuration was NOT bit-identical on this box (it agrees with the baseline on "
+              f"{ctl_close:.4f} of the pixels): comparing within RUN_VS_RUN limits, pixels against that yardstick")
     (rec_a, stats_a), (rec_b, stats_b) = run_a, run_b
     keys = stats_keys if stats_keys is not None else sorted(k for k in stats_a if k.startswith("Trial_"))
     assert keys and sorted(k for k in stats_b if k.startswith("Trial_")) == sorted(k for k in stats_a if k.startswith("Trial_"))
@@ -83,7 +92,7 @@ def assert_same_attack(run_a, run_b, stats_keys=None, control=None):
     assert stats_a["opt_value"] == pytest.approx(stats_b["opt_value"], rel=RUN_VS_RUN["opt_value_rel"])
     a, b = rec_a.detach().cpu().numpy(), rec_b.detach().cpu().numpy()
     close = np.isclose(a, b, rtol=RUN_VS_RUN["pixel_tol"], atol=RUN_VS_RUN["pixel_tol"]).mean()
-    assert close >= RUN_VS_RUN["pixel_fraction"], close
+    assert close >= pixel_fraction, (close, pixel_fraction)
 
 
 def pytest_collection_modifyitems(config, items):

@@ -134,7 +134,7 @@ print(json.dumps(dict(report=report, solo_ms=solo, pairs=pairs, distinct=len({s.
         print(f"  {mode}, {decoys} earlier streams: candidates {rec['report']['candidates']}, collisions skipped {rec['report']['collisions']}, "
               f"solo {rec['solo_ms']:.3f} ms, worst pair {max(rec['pairs'].values()):.3f} ms, picked {rec['picked']}")
         assert rec["distinct"] == 4 and rec["cached"] == [True, True, True] and not rec["report"].get("incomplete")
-        assert max(rec["pairs"].values()) <= 3.0 * rec["solo_ms"], rec  # no two of the chosen streams collide
+        assert max(rec["pairs"].values()) <= 1.9 * rec["solo_ms"], rec  # no two of the chosen streams collide (clean ~1.2x, colliding ~3.1x)
         if mode == "scrambled":
             assert rec["picked"] == [0, 1, 2, 3]
             assert [(c["candidate"], c["with_chosen"]) for c in rec["report"]["collisions"]] == [(2, 0), (4, 1), (6, 2)]

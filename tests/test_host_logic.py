@@ -588,3 +588,24 @@ def test_pending_batchnorm_absorbs_residual_and_relu_without_changing_the_model(
     calls.clear()
     hip(x)
     assert calls == [(False, False)] * 3
+
+
+def test_design_tables_are_generated_from_the_committed_profiles():
+    """DESIGN.md section 6's round-4 tables are the output of scripts/design_tables.py over the files under profiles/: a number
+    in the text cannot drift from the committed evidence (round 3 had a quoted 40.2 / 47.6 us that the summary file no longer
+    showed).  Regenerate with `python scripts/design_tables.py --write`."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("design_tables", os.path.join(root, "scripts", "design_tables.py"))
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    text = open(os.path.join(root, "DESIGN.md")).read()
+    assert module.BEGIN in text and module.END in text
+    block = text[text.index(module.BEGIN): text.index(module.END) + len(module.END)]
+    assert block == module.build(), "DESIGN.md is stale: run `python scripts/design_tables.py --write`"
+    # the files the block quotes exist
+    for name in ("r4_bench_n1.json", "r4_1trial_gap_census.json", "r4_node_cost_probe.jsonl", "r4_inflight_pipes_probe.jsonl",
+                 "r4_bench_kernel_summary.txt"):
+        assert os.path.exists(os.path.join(root, "profiles", name)), name
