@@ -1045,12 +1045,20 @@ class _PendingBatchNorm(torch.Tensor):
         self = torch.Tensor._make_wrapper_subclass(cls, x.shape, dtype=x.dtype, device=x.device, requires_grad=False)
         self._module, self._x, self._sink, self._tap = module, x, sink, tap
         self._residual, self._value = None, None
+        self._graph_expected = torch.is_grad_enabled() and x.requires_grad
         if tap is not None:
             tap.pending = self  # the DeepInversion prior launches whatever is still waiting when it is evaluated
         return self
 
     def launch(self, relu=False):
         """Run the kernel now (the only place this object's computation happens)."""
+        if self._graph_expected and not torch.is_grad_enabled():
+            # Created where autograd was recording, consumed where it is not: the consumer is almost certainly the forward of a
+            # custom autograd.Function, which received this metadata-only wrapper as an input and therefore has no autograd
+            # edge to the BatchNorm input -- its gradient would silently stop here.  Fail loudly instead.
+            raise RuntimeError("An eval-mode BatchNorm output was handed to a custom autograd.Function (or consumed inside a "
+                               "no_grad block) before any ordinary operation used it; the deferred BatchNorm launch cannot carry "
+                               "an autograd edge there.  Set cfg.impl.fuse_bn_relu=False (or BREACH_HIP_FUSE_BN_RELU=0).")
         return _launch_eval_bn(self._module, self._x, self._sink, self._tap, self._residual, relu)
 
     def value(self):
@@ -1159,6 +1167,8 @@ class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):
         return self._runs_on_hip(x)
 
     def forward(self, x):
+        if isinstance(x, _PendingBatchNorm):  # BatchNorm fed directly by a BatchNorm: an autograd.Function must never see the
+            x = x.value()                      # metadata-only wrapper as an input (it carries no autograd edge)
         sink = self.__dict__.pop("_bn_stats_sink", None)  # set by a DeepInversion tap for this one call
         tap = self.__dict__.pop("_bn_tap", None)           # likewise: the tap whose token this forward has to emit
         if tap is not None and not self._runs_on_hip(x):   # (the tap asked `accepts_stats_sink` on the same x: not reached)
@@ -1310,6 +1320,8 @@ class _HipLayerNorm(torch.nn.LayerNorm):
     kernel F when it normalises the last dimension of an fp32 ROCm tensor; anything else takes the stock path."""
 
     def forward(self, x):
+        if isinstance(x, _PendingBatchNorm):
+            x = x.value()
         if (len(self.normalized_shape) == 1 and x.is_cuda and x.dtype == torch.float32 and x.numel() > 0
                 and x.shape[-1] == self.normalized_shape[0] and x.numel() < 2 ** 31 and not _under_functorch(x)):
             return _LayerNormFunction.apply(x, self.weight, self.bias, self.eps)

@@ -354,6 +354,12 @@ def bn_statistic(x, running_mean, running_var, weight=1.0):
     return _BnStatFunction.apply(plan, None, x)
 
 
+def resolve_pending(x):
+    """A not-yet-launched eval-BatchNorm output (attacker._PendingBatchNorm) as an ordinary tensor: hooks that hand a module's
+    input to an autograd.Function must not pass the metadata-only wrapper on (it carries no autograd edge)."""
+    return x.value() if type(x).__name__ == "_PendingBatchNorm" else x
+
+
 def ctypes_offset(tensor, elements):
     from ctypes import c_void_p
 
@@ -377,7 +383,7 @@ class _BnInputTap:
         self.handle = module.register_forward_pre_hook(self)
 
     def __call__(self, module, inputs):
-        x = inputs[0]
+        x = resolve_pending(inputs[0])
         if not (torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32):
             raise RuntimeError("HIP DeepInversion prior needs fp32 activations on a ROCm device (no CPU fallback).")
         if not x.is_contiguous():
@@ -535,7 +541,7 @@ class _LastLinearInput:
         self.handle = module.register_forward_hook(self)
 
     def __call__(self, module, inputs, output):
-        self.features = inputs[0]
+        self.features = resolve_pending(inputs[0])
 
     def close(self):
         self.handle.remove()

@@ -578,6 +578,38 @@ def test_pending_batchnorm_absorbs_residual_and_relu_without_changing_the_model(
             (ga,) = torch.autograd.grad((hip(xa) ** 2).sum(), xa)
             (gb,) = torch.autograd.grad((ref(xb) ** 2).sum(), xb)
             torch.testing.assert_close(ga, gb, rtol=1e-4, atol=1e-5)
+    # a BatchNorm fed DIRECTLY by a BatchNorm: the waiting output is resolved at the module boundary (an autograd.Function must
+    # never receive the metadata-only wrapper as an input -- it carries no autograd edge, the gradient would silently stop)
+    chain = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.BatchNorm2d(4), torch.nn.ReLU()).eval()
+    for m in chain:
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.5, 2)
+    chain_hip = A.use_affine_eval_batchnorm(copy.deepcopy(chain), "hip")
+    for m in chain_hip:
+        if isinstance(m, A._EvalAffineBatchNorm2d):
+            m._runs_on_hip = lambda x: True
+    xc = torch.randn(2, 3, 8, 8)
+    xa, xb = xc.clone().requires_grad_(True), xc.clone().requires_grad_(True)
+    calls.clear()
+    (ga,) = torch.autograd.grad((chain_hip(xa) ** 2).sum(), xa)
+    (gb,) = torch.autograd.grad((chain(xb) ** 2).sum(), xb)
+    assert calls == [(False, False), (False, True)]
+    torch.testing.assert_close(ga, gb, rtol=1e-4, atol=1e-5)
+    # ... and a THIRD-PARTY autograd.Function fed directly by a BatchNorm fails loudly instead of dropping its gradient
+    class Twice(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    with pytest.raises(RuntimeError, match="custom autograd.Function"):
+        Twice.apply(chain_hip[:2](xc.clone().requires_grad_(True)))
+    with torch.no_grad():  # whole forward without autograd: nothing to lose, no error
+        torch.testing.assert_close(chain_hip(xc), chain(xc), rtol=1e-5, atol=1e-5)
     # switched off: the modules launch immediately, nothing is deferred
     monkeypatch.setenv("BREACH_HIP_FUSE_BN_RELU", "0")
     calls.clear()
