@@ -743,6 +743,8 @@ def assemble_resnet18_24k():
     twins = [np.load(os.path.join(FULL_DIR, f"run{i}.npz")) for i in range(1, FULL_TWINS + 1)
              if os.path.exists(os.path.join(FULL_DIR, f"run{i}.npz"))]
     main["history"] = main["history"].astype(np.float32)  # the reference's values ARE fp32 (.item() of an fp32 scalar)
+    if "forced_grad" in main:  # a worker started before the bf16 packing existed wrote fp32: pack here
+        main["forced_grad_bf16"] = np.stack([_bf16_bits(torch.as_tensor(g)) for g in main.pop("forced_grad")])
     main.update(twin_history=np.stack([t["history"] for t in twins]).astype(np.float32),
                 twin_psnr=np.asarray([t["psnr"] for t in twins]), twin_opt_value=np.asarray([t["opt_value"] for t in twins]),
                 twin_rec_mean=np.asarray([t["rec_mean"] for t in twins]), twin_rec_std=np.asarray([t["rec_std"] for t in twins]),
