@@ -257,9 +257,13 @@ def test_resnet18_24k_end_of_run_against_the_reference_runs(golden_dir, resnet18
     """Three HIP runs of the full 24 000 iterations from the reference's three starting points (nominal x0 and two starts
     <= 16 ulp away), in flight together on the GPU, against the three runs of the unmodified reference: the loss right after
     each milestone, the final loss, the rescored opt_value and PSNR.  Hard-sign Adam on a ReLU network is chaotic (the
-    reference's own three runs differ from each other), so each HIP value must lie in the reference's range widened by 3 of
-    its standard deviations (at least 2 %), the means must agree within 4 standard errors, and mean PSNR within 0.1 dB or the
-    reference's own spread, whichever is larger.  The 8-start version of this comparison: scripts/config_runs.py --starts 8."""
+    reference's own three runs differ from each other; over EIGHT starts its end-of-run loss has a standard deviation of
+    1.7 %, tests/golden/attack_resnet18_long.npz), and three samples underestimate that spread (at iteration 999 they
+    happen to lie within 1.3 % of each other while eight HIP starts cover 3.5 %, profiles/r4_config1_24k_8starts.log), so
+    each HIP value must lie in the reference's range widened by 3 of its standard deviations or 5 % (= 3 sigma of the
+    eight-run spread), whichever is larger, the means must agree within 4 standard errors, and mean PSNR within 0.1 dB or the
+    reference's own spread, whichever is larger.  The tight checks of this horizon are the teacher-forced ones above; the
+    8-start version of this comparison: scripts/config_runs.py --only 24k --starts 8."""
     from breaching_amd import get_attack_config, prepare_attack
     from breaching_amd.cases import initial_candidate, psnr, ulp_perturb
 
@@ -309,7 +313,7 @@ def test_resnet18_24k_end_of_run_against_the_reference_runs(golden_dir, resnet18
         se = np.sqrt(sr ** 2 / len(r) + sh ** 2 / len(h))
         print(f"  {name:12s} reference {mr:.6f} +- {sr:.6f} [{r.min():.6f}, {r.max():.6f}]   hip {mh:.6f} +- {sh:.6f} "
               f"[{h.min():.6f}, {h.max():.6f}]   mean diff {abs(mh - mr) / max(se, 1e-30):.2f} standard errors")
-        widen = max(3 * sr, 0.02 * abs(mr)) if name != "psnr" else max(3 * sr, PSNR_TOL_DB)
+        widen = max(3 * sr, 0.05 * abs(mr)) if name != "psnr" else max(3 * sr, PSNR_TOL_DB)
         if h.min() < r.min() - widen or h.max() > r.max() + widen:
             failures.append(f"{name}: a run lies outside the reference range [{r.min():.6f}, {r.max():.6f}] widened by {widen:.6f}")
         if abs(mh - mr) > max(4.0 * se, 1e-4 * abs(mr)) and name != "psnr":
