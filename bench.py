@@ -106,10 +106,20 @@ def hbm_resident_leg(device, reps=30):
         torch.cuda.synchronize(device)
         t = plan.drain_timers()
         f, e, b = (sum(sorted(t[k])[:-5]) / (len(t[k]) - 5) for k in ("fwd", "fin", "bwd"))
+        # the same forward launch with nothing but its own finalize between repetitions: in the triple above every forward
+        # follows a backward that has just written 344 MB, whose write-back competes with the forward's reads (the in-loop
+        # condition: there autograd has just written the reconstructed list)
+        plan.enable_timing()
+        for _ in range(reps):
+            plan.forward(kind, rec, 1.0, 0.1, 1e-7, weights)
+        torch.cuda.synchronize(device)
+        alone = plan.drain_timers()["fwd"]
+        fa = sum(sorted(alone)[:-5]) / (len(alone) - 5)
         out[kind_name] = dict(fwd_us=round(f, 2), finalize_us=round(e, 2), bwd_us=round(b, 2),
                               fwd_GBs=round(2 * n * 4 / f / 1e3, 1), frac=round(2 * n * 4 / f / 1e3 / HBM_PEAK_GBS, 4),
                               stage_frac=round(2 * n * 4 / (f + e) / 1e3 / HBM_PEAK_GBS, 4),
-                              bwd_GBs=round(3 * n * 4 / b / 1e3, 1), bwd_frac=round(3 * n * 4 / b / 1e3 / HBM_PEAK_GBS, 4))
+                              bwd_GBs=round(3 * n * 4 / b / 1e3, 1), bwd_frac=round(3 * n * 4 / b / 1e3 / HBM_PEAK_GBS, 4),
+                              fwd_not_behind_a_writer_us=round(fa, 2), frac_not_behind_a_writer=round(2 * n * 4 / fa / 1e3 / HBM_PEAK_GBS, 4))
     plan.timers = None
     return out
 
@@ -128,6 +138,62 @@ def cpu_anchor_ratio():
         return dict(port_over_reference=rec.get("port_over_reference"), file=os.path.basename(paths[-1]), threads=rec.get("threads"))
     except Exception:
         return None
+
+
+def cpu_baseline_leg(model_name, iters, cpu_threads=0):
+    """The reference's CPU path on this box's host cores, same workload, `iters` loop iterations.  kind "reference": the
+    UNMODIFIED reference through oracle/ref_shim.py when a checkout is importable (a (2 + iters)-iteration reconstruct() minus a
+    2-iteration one isolates the loop from the model rebuild and the final rescoring, as scripts/cpu_baseline_anchor.py does);
+    kind "port": oracle/restate.py, with the committed port / reference anchor ratio next to it.  Needs no GPU."""
+    import torch
+
+    import breaching_amd
+    from breaching_amd.cases import build_case, initial_candidate
+
+    host_cores = os.cpu_count() or 1
+    # torch's CPU convolutions at B = 1 peak at 16 threads on the 256-logical-core host of the GPU box and LOSE beyond it
+    # (profiles/r4_cpu_thread_sweep.json: 8 / 16 / 32 / 64 / 128 threads = 15.7 / 18.3 / 8.3 / 3.3 / 0.9 it/s): the baseline is
+    # timed at its best thread count, not at os.cpu_count(); --cpu-threads overrides
+    threads = cpu_threads if cpu_threads > 0 else min(host_cores, 16)
+    torch.set_num_threads(threads)
+    cpu_case = build_case(model_name, "ImageNet", 1, device="cpu")
+    x0_cpu = initial_candidate(cpu_case.data_cfg, 1)
+    reference_root = os.environ.get("BREACHING_REFERENCE", "/root/reference")
+    kind, seconds, note = "port", None, None
+    if os.path.isdir(os.path.join(reference_root, "breaching")):
+        try:  # the unmodified reference, exactly as oracle/make_golden.py runs it
+            from oracle.make_golden import _cfg as reference_cfg
+            from oracle.make_golden import _run_reference_attack
+
+            def timed_reference(its):
+                tc = time.perf_counter()
+                _run_reference_attack(reference_cfg("invertinggradients", [f"optim.max_iterations={its}", "optim.callback=100000"]), cpu_case, x0_cpu)
+                return time.perf_counter() - tc
+
+            timed_reference(2)  # warm-up: allocator, oneDNN primitives, TorchScript
+            short = timed_reference(2)
+            seconds, kind = timed_reference(2 + iters) - short, "reference"
+            note = (f"{iters} loop iterations of the same {model_name}/224 invertinggradients workload through the UNMODIFIED reference "
+                    f"({reference_root} via oracle/ref_shim.py; torch {torch.__version__} CPU): a (2 + {iters})-iteration reconstruct() minus "
+                    "a 2-iteration one, after a warm-up call")
+        except Exception as exc:
+            note = f"reference checkout found but not runnable ({exc!r}); "
+    if seconds is None:
+        from oracle import restate
+
+        cpu_cfg = breaching_amd.get_attack_config("invertinggradients")
+        restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
+                           initial_data=x0_cpu, max_iterations=2)  # warm-up (allocator, oneDNN primitives)
+        timing = []
+        restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
+                           initial_data=x0_cpu, max_iterations=iters, timing=timing)
+        seconds = timing[0]
+        note = (note or "") + (f"{iters} iterations of the same {model_name}/224 invertinggradients workload through oracle/restate.py (torch "
+                               f"{torch.__version__} CPU; no reference checkout on this box), after 2 warm-up iterations")
+    out = dict(value=round(iters / seconds, 3), unit="attack iterations/s", cores=threads, host_cpu_count=host_cores, kind=kind, sample=note)
+    if kind == "port":
+        out["anchor"] = cpu_anchor_ratio()  # how the port relates to the unmodified reference on equal threads
+    return out
 
 
 def parse_args():
@@ -411,53 +477,7 @@ def main():
     # ---- CPU baseline (rank 0, N == 1 only) ---------------------------------------------------------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
-        host_cores = os.cpu_count() or 1
-        # torch's CPU convolutions at B = 1 peak at 16 threads on the 256-logical-core host of the GPU box and LOSE beyond it
-        # (profiles/r4_cpu_thread_sweep.json: 8 / 16 / 32 / 64 / 128 threads = 15.7 / 18.3 / 8.3 / 3.3 / 0.9 it/s): the baseline is
-        # timed at its best thread count, not at os.cpu_count(); --cpu-threads overrides
-        threads = args.cpu_threads if args.cpu_threads > 0 else min(host_cores, 16)
-        torch.set_num_threads(threads)
-        cpu_case = build_case(args.model, "ImageNet", 1, device="cpu")
-        x0_cpu = initial_candidate(cpu_case.data_cfg, 1)
-        iters = args.cpu_baseline_iters
-        reference_root = os.environ.get("BREACHING_REFERENCE", "/root/reference")
-        kind, seconds, note = "port", None, None
-        if os.path.isdir(os.path.join(reference_root, "breaching")):
-            try:  # the unmodified reference, exactly as oracle/make_golden.py runs it
-                from oracle.make_golden import _cfg as reference_cfg
-                from oracle.make_golden import _run_reference_attack
-
-                def timed_reference(its):
-                    tc = time.perf_counter()
-                    _run_reference_attack(reference_cfg("invertinggradients", [f"optim.max_iterations={its}", "optim.callback=100000"]), cpu_case, x0_cpu)
-                    return time.perf_counter() - tc
-
-                timed_reference(2)  # warm-up: allocator, oneDNN primitives, TorchScript
-                # a reconstruct() call includes the model rebuild and the final rescoring: a 2-iteration call is subtracted to
-                # isolate the loop (same method as scripts/cpu_baseline_anchor.py)
-                short = timed_reference(2)
-                seconds, kind = timed_reference(2 + iters) - short, "reference"
-                note = (f"{iters} loop iterations of the same ResNet-18/224 invertinggradients workload through the UNMODIFIED reference "
-                        f"({reference_root} via oracle/ref_shim.py; torch {torch.__version__} CPU): a (2 + {iters})-iteration reconstruct() minus "
-                        "a 2-iteration one, after a warm-up call")
-            except Exception as exc:
-                note = f"reference checkout found but not runnable ({exc!r}); "
-        if seconds is None:
-            from oracle import restate
-
-            cpu_cfg = breaching_amd.get_attack_config("invertinggradients")
-            restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
-                               initial_data=x0_cpu, max_iterations=2)  # warm-up (allocator, oneDNN primitives)
-            timing = []
-            restate.run_attack(cpu_case.model, cpu_case.loss_fn, cpu_cfg, cpu_case.server_payload, cpu_case.shared_data,
-                               initial_data=x0_cpu, max_iterations=iters, timing=timing)
-            seconds = timing[0]
-            note = (note or "") + (f"{iters} iterations of the same ResNet-18/224 invertinggradients workload through oracle/restate.py (torch "
-                                   f"{torch.__version__} CPU; no reference checkout on this box), after 2 warm-up iterations")
-        cpu_baseline = dict(value=round(iters / seconds, 3), unit="attack iterations/s", cores=threads, host_cpu_count=host_cores,
-                            kind=kind, sample=note)
-        if kind == "port":
-            cpu_baseline["anchor"] = cpu_anchor_ratio()  # how the port relates to the unmodified reference on equal threads
+        cpu_baseline = cpu_baseline_leg(args.model, args.cpu_baseline_iters, args.cpu_threads)
 
     if rank == 0:
         line = {

@@ -3,7 +3,7 @@
 bench.py times oracle/restate.py on the GPU box's host cores, because the unmodified reference does not exist there.  This
 script times BOTH -- the unmodified reference (through oracle/ref_shim.py) and the restatement -- on the same cores of the
 build container, same workload (ResNet-18 / 224 x 224, invertinggradients), so the ratio ties the port's iterations/s to the
-reference's.  Output: profiles/r2_cpu_baseline_anchor.json.   python scripts/cpu_baseline_anchor.py [--iters 20]
+reference's.  Output: profiles/r4_cpu_baseline_anchor.json (round 2: r2_...).   python scripts/cpu_baseline_anchor.py [--iters 20]
 """
 import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -48,5 +48,5 @@ out["reference_iterations_per_s"] = round(args.iters / (t_ref_long - t_ref_short
 out["port_iterations_per_s"] = round(args.iters / timed_port(args.iters), 3)
 out["port_over_reference"] = round(out["port_iterations_per_s"] / out["reference_iterations_per_s"], 3)
 print(json.dumps(out, indent=1))
-with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r2_cpu_baseline_anchor.json"), "w") as f:
+with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r4_cpu_baseline_anchor.json"), "w") as f:
     json.dump(out, f, indent=1)

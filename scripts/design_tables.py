@@ -97,7 +97,7 @@ def build():
         for kind in ("cosine-similarity", "tag-euclidean"):
             if kind in h:
                 e = h[kind]
-                L.append(f"| **HBM-resident** list (BERT-base, {h['elements'] / 1e6:.2f} M elements, {2 * h['elements'] * 4 / 1e6:.1f} MB per forward launch), {kind}, in the SAME run | fwd {e['fwd_us']:.1f} us = **{e['frac']:.3f}** (stage {e['stage_frac']:.3f}); bwd {e['bwd_us']:.1f} us = **{e['bwd_frac']:.3f}** | same (`roofline.hbm_resident`) |")
+                L.append(f"| **HBM-resident** list (BERT-base, {h['elements'] / 1e6:.2f} M elements, {2 * h['elements'] * 4 / 1e6:.1f} MB per forward launch), {kind}, in the SAME run | fwd {e['fwd_us']:.1f} us = **{e['frac']:.3f}** (stage {e['stage_frac']:.3f}" + (f"; not behind a writer: {e['fwd_not_behind_a_writer_us']:.1f} us = {e['frac_not_behind_a_writer']:.3f}" if "frac_not_behind_a_writer" in e else "") + f"); bwd {e['bwd_us']:.1f} us = **{e['bwd_frac']:.3f}** | same (`roofline.hbm_resident`) |")
         c = b.get("cpu_baseline")
         if c:
             anchor = c.get("anchor") or {}

@@ -641,3 +641,28 @@ def test_design_tables_are_generated_from_the_committed_profiles():
     for name in ("r4_bench_n1.json", "r4_1trial_gap_census.json", "r4_node_cost_probe.jsonl", "r4_inflight_pipes_probe.jsonl",
                  "r4_bench_kernel_summary.txt"):
         assert os.path.exists(os.path.join(root, "profiles", name)), name
+
+
+def test_bench_cpu_baseline_is_the_unmodified_reference_when_a_checkout_is_importable(monkeypatch):
+    """bench.py's `cpu_baseline` leg (no GPU needed): with the reference checkout present (this container) it times the
+    UNMODIFIED reference (`kind: "reference"`); pointed at a directory without one (the GPU box) it times the port and reports
+    the committed port / reference anchor ratio."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    threads = torch.get_num_threads()
+    try:
+        if os.path.isdir(os.path.join(os.environ.get("BREACHING_REFERENCE", "/root/reference"), "breaching")):
+            leg = bench.cpu_baseline_leg("resnet18", 2, cpu_threads=4)
+            assert leg["kind"] == "reference" and leg["value"] > 0 and leg["cores"] == 4 and "UNMODIFIED reference" in leg["sample"]
+            assert "anchor" not in leg
+        monkeypatch.setenv("BREACHING_REFERENCE", "/nonexistent")
+        leg = bench.cpu_baseline_leg("resnet18", 2, cpu_threads=4)
+        assert leg["kind"] == "port" and leg["value"] > 0 and "oracle/restate.py" in leg["sample"]
+        assert leg["anchor"]["port_over_reference"] == pytest.approx(1.0, abs=0.1) and leg["anchor"]["file"].endswith("cpu_baseline_anchor.json")
+    finally:
+        torch.set_num_threads(threads)
