@@ -883,8 +883,10 @@ def test_deepinversion_coefficients_are_bound_to_their_forward_pass(hip_lib):
             prior.release_graph()
             (again,) = torch.autograd.grad(va, xa)
             (gb,) = torch.autograd.grad(vb, xb)
-            assert torch.equal(want, again)
-            assert not torch.allclose(gb, want)
+            # the same graph backpropagated twice: equal up to the vendor convolution kernels' own run-to-run rounding, and
+            # nowhere near what the LATER pass's coefficients would give
+            torch.testing.assert_close(again, want, rtol=1e-5, atol=1e-7)
+            assert not torch.allclose(gb, want, rtol=1e-2, atol=1e-4)
         finally:
             os.environ.pop("BREACH_HIP_BN_FUSED_TAP", None)
 
