@@ -119,7 +119,7 @@ _PROTOTYPES = {
     "bh_bn_bwd_accumulate": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bh_bn_eval_fwd": (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_int32, c_int32, c_void_p]),
     "bh_bn_eval_slabs": (c_int32, [c_int32, c_int32, c_int32]),
-    "bh_bn_eval_bwd": (c_int, [c_void_p] * 13 + [c_int32, c_int32, c_int32, c_void_p]),
+    "bh_bn_eval_bwd": (c_int, [c_void_p] * 14 + [c_int32, c_int32, c_int32, c_void_p]),
     "bh_bn_eval_bwd_bwd": (c_int, [c_void_p] * 14 + [c_int32, c_int32, c_int32, c_void_p]),
     "bh_ln_fwd": (c_int, [c_void_p] * 6 + [c_int32, c_int32, ctypes.c_float, c_void_p]),
     "bh_ln_bwd": (c_int, [c_void_p] * 8 + [c_int32, c_int32, c_void_p]),

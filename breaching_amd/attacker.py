@@ -899,10 +899,18 @@ class _EvalBNFunction(torch.autograd.Function):
     block (`_PendingBatchNorm` decides when) -- and the two backward orders carry the ReLU mask (read back from y) and the
     residual's gradient.
 
-    With `tap` (a DeepInversion tap of this layer, priors._BnInputTap) the node has a second, 0-dim output: the token through
-    which the prior's statistic node sends back d objective / d total.  When that token gradient arrives together with gy,
-    the backward launch adds the prior's term gout * (A_c + B_c * x) to gx (it reads x anyway): the prior's backward costs
-    no launch and no traffic of its own (regularizers.py:222-227 / deepinversion.py:93-103, math only)."""
+    Outputs: y, an alias `xp` of the input, and -- with `tap` (a DeepInversion tap of this layer, priors._BnInputTap) -- a 0-dim
+    token.  Both extras exist to let autograd hand this node EVERYTHING that flows back to this BatchNorm input in one call, so
+    that one launch writes the sum and the engine has nothing left to accumulate:
+      * `xp` is what the first-order backward differentiates with respect to (instead of x itself): in the attack's outer pass
+        the derivative of that backward sends its d_x to `xp`, i.e. to this node, which adds it to gy * s_c inside
+        bh_bn_eval_bwd (`gx_add`) -- otherwise two nodes each send a gradient to x's producer and autograd adds them with an
+        ATen launch per layer;
+      * the token is how the prior's statistic node sends back d objective / d total: the launch adds gout * (A_c + B_c * x)
+        (it reads x anyway): the prior's backward costs no launch and no traffic of its own (regularizers.py:222-227 /
+        deepinversion.py:93-103, math only).
+    The engine calls a node only when the gradients of all its used outputs have arrived: correct by construction, no
+    assumption about execution order."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, inv_std, mean_inv, stats=None, tap=None, residual=None, relu=False):
@@ -917,26 +925,24 @@ class _EvalBNFunction(torch.autograd.Function):
             _lib.check(lib.bh_bn_eval_fwd(_lib.ptr(xk), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(inv_std), _lib.ptr(mean_inv),
                                           _lib.ptr(y), _lib.ptr(stats), _lib.ptr(rk), int(bool(relu)), B, C, hw,
                                           _lib.current_stream_handle(x.device)), "bh_bn_eval_fwd")
-        # the INPUT itself is saved (not the detached kernel view): the backward below is differentiable with respect to it;
-        # with a ReLU the OUTPUT is saved too -- its sign is the mask of both backward orders
-        ctx.save_for_backward(x, weight, inv_std, mean_inv, *([y] if relu else []))
+        xp = x.view_as(x)
+        # the alias of the INPUT is saved (not the detached kernel view): the backward below is differentiable with respect to
+        # it; with a ReLU the OUTPUT is saved too -- its sign is the mask of both backward orders
+        ctx.save_for_backward(xp, weight, inv_std, mean_inv, *([y] if relu else []))
         ctx.has_bias, ctx.relu, ctx.has_residual = bias is not None, bool(relu), residual is not None
-        ctx.tap = None
-        if tap is None:
-            return y
-        ctx.tap = (tap.record, tap.layer)  # the record of THIS pass: its coefficients are what the backward applies
+        ctx.tap = None if tap is None else (tap.record, tap.layer)  # the record of THIS pass: its coefficients are what the backward applies
         ctx.set_materialize_grads(False)
-        return y, x.new_empty(())
+        return (y, xp) if tap is None else (y, xp, x.new_empty(()))
 
     @staticmethod
-    def backward(ctx, gy, g_token=None):
-        x, weight, inv_std, mean_inv, *rest = ctx.saved_tensors
+    def backward(ctx, gy, g_xp=None, g_token=None):
+        xp, weight, inv_std, mean_inv, *rest = ctx.saved_tensors
         mask = rest[0].detach() if ctx.relu else None  # a constant of every order (ReLU'' = 0 almost everywhere)
         none = (None,) * 9
         if g_token is None or ctx.tap is None:
             if gy is None:
-                return none
-            gx, gw, gb, gr = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv, mask, None, ctx.has_residual)
+                return (g_xp,) + none[1:]
+            tap = None
         else:
             if torch.is_grad_enabled():
                 raise NotImplementedError("The DeepInversion term fused into the BatchNorm backward supports no create_graph "
@@ -944,9 +950,12 @@ class _EvalBNFunction(torch.autograd.Function):
             record, layer = ctx.tap
             _, coef_ptr = record.layer_coefficients(layer)
             if gy is None:
-                gy = torch.zeros_like(x)
-            gout = g_token.detach().reshape(1).to(torch.float32)
-            gx, gw, gb, gr = _EvalBNGradFunction.apply(gy, x, weight, inv_std, mean_inv, mask, (coef_ptr, gout, record.coef), ctx.has_residual)
+                gy = torch.zeros_like(xp)
+            tap = (coef_ptr, g_token.detach().reshape(1).to(torch.float32), record.coef)
+        fold = g_xp is not None and not torch.is_grad_enabled()  # the launch adds it; under create_graph a differentiable add does
+        gx, gw, gb, gr = _EvalBNGradFunction.apply(gy, xp, weight, inv_std, mean_inv, mask, tap, ctx.has_residual, g_xp if fold else None)
+        if g_xp is not None and not fold:
+            gx = gx + g_xp
         return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None, None, gr, None
 
 
@@ -955,16 +964,17 @@ class _EvalBNGradFunction(torch.autograd.Function):
     launch (bh_bn_eval_bwd_bwd).  PyTorch's decomposition of the same three orders is ~35 launches per layer (+ 6 for a ReLU).
     `mask`: the forward output when the forward applied a ReLU (gy is masked by [y > 0] first); `tap` = (address of the layer's
     (A_c, B_c) pairs, gout, owner of that memory): gx additionally receives gout * (A_c + B_c * x); `want_residual`: also
-    return the masked gradient itself, the gradient of the forward's residual input."""
+    return the masked gradient itself, the gradient of the forward's residual input; `gx_add`: a constant added to gx."""
 
     @staticmethod
-    def forward(ctx, gy, x, weight, inv_std, mean_inv, mask=None, tap=None, want_residual=False):
+    def forward(ctx, gy, x, weight, inv_std, mean_inv, mask=None, tap=None, want_residual=False, gx_add=None):
         lib = _lib.load()
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         gyk = _vector_ready(gy.detach().to(torch.float32), hw)
         xk = _vector_ready(x.detach(), hw)
         mk = None if mask is None else _vector_ready(mask.detach(), hw)
+        ak = None if gx_add is None else _vector_ready(gx_add.detach().to(torch.float32), hw)
         gx = torch.empty_like(xk)
         gr = torch.empty_like(xk) if want_residual else None
         gw = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -975,10 +985,10 @@ class _EvalBNGradFunction(torch.autograd.Function):
         with torch.cuda.device(x.device):
             _lib.check(lib.bh_bn_eval_bwd(_lib.ptr(gyk), _lib.ptr(xk), _lib.ptr(weight), _lib.ptr(inv_std), _lib.ptr(mean_inv),
                                           _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), coef_ptr, gout, _lib.ptr(mk), _lib.ptr(gr),
-                                          B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd")
+                                          _lib.ptr(ak), B, C, hw, _lib.current_stream_handle(x.device)), "bh_bn_eval_bwd")
         ctx.save_for_backward(gyk, xk, weight, inv_std, mean_inv, *([mk] if mk is not None else []))
         ctx.set_materialize_grads(False)
-        ctx.had_tap, ctx.masked = tap is not None, mk is not None
+        ctx.extra_terms, ctx.masked = (tap is not None or gx_add is not None), mk is not None
         return gx, gw, gb, gr
 
     @staticmethod
@@ -987,11 +997,11 @@ class _EvalBNGradFunction(torch.autograd.Function):
         lib = _lib.load()
         gy, x, weight, inv_std, mean_inv, *rest = ctx.saved_tensors
         mask = rest[0] if ctx.masked else None
-        none = (None,) * 8
+        none = (None,) * 9
         if ggx is None and ggw is None and ggb is None and ggr is None:
             return none
-        if ctx.had_tap:
-            raise NotImplementedError("No derivative of the BatchNorm backward with the DeepInversion term fused in.")
+        if ctx.extra_terms:
+            raise NotImplementedError("No derivative of the BatchNorm backward with the DeepInversion term / another gradient folded in.")
         B, C = x.shape[0], x.shape[1]
         hw = x[0, 0].numel()
         ggx = None if ggx is None else _vector_ready(ggx.to(torch.float32), hw)
@@ -1010,17 +1020,16 @@ class _EvalBNGradFunction(torch.autograd.Function):
                                               _lib.ptr(inv_std), _lib.ptr(mean_inv), _lib.ptr(d_gy), _lib.ptr(d_x), _lib.ptr(d_w),
                                               _lib.ptr(ws), _lib.ptr(mask), _lib.ptr(ggr), B, C, hw, _lib.current_stream_handle(x.device)),
                        "bh_bn_eval_bwd_bwd")
-        return d_gy, d_x, d_w, None, None, None, None, None
+        return d_gy, d_x, d_w, None, None, None, None, None, None
 
 
 def _launch_eval_bn(module, x, sink, tap, residual, relu):
     """One kernel E forward launch of `module` on `x` (+ residual, ReLU); hands the DeepInversion tap its token."""
     inv_std, mean_inv = module._frozen_statistics()
-    args = (x, module.weight, module.bias, inv_std, mean_inv, sink, tap, residual, relu)
-    if tap is None:
-        return _EvalBNFunction.apply(*args)
-    y, tap.token = _EvalBNFunction.apply(*args)
-    return y
+    out = _EvalBNFunction.apply(x, module.weight, module.bias, inv_std, mean_inv, sink, tap, residual, relu)
+    if tap is not None:
+        tap.token = out[2]
+    return out[0]  # out[1], the input's alias, lives on only as the node's saved tensor
 
 
 _RELU_OUT_OF_PLACE = (torch.relu, torch.nn.functional.relu, torch.Tensor.relu)

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
                                                              float* __restrict__ gw, float* __restrict__ gb,
                                                              double* __restrict__ part, const float* __restrict__ tap_coef,
                                                              const float* __restrict__ tap_gout, const float* __restrict__ ymask,
-                                                             float* __restrict__ gres, int B, int C, int HW, int S, int narrow) {
+                                                             float* __restrict__ gres, const float* __restrict__ add_in, int B, int C,
+                                                             int HW, int S, int narrow) {
   __shared__ double lds[bh::kWavesPerBlock * 2];
   const ChannelWalk w = channel_of(C, S, narrow != 0);
   double v[2] = {0.0, 0.0};  // sum gz, sum gz * x   (gz = gy behind the ReLU mask, = gy without one)
@@ -189,11 +190,13 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
         }
         if (gres) reinterpret_cast<float4*>(gres)[at] = g;
         if (gx) {
-          if (tap_coef)
-            reinterpret_cast<float4*>(gx)[at] = make_float4(g.x * s + fmaf(tb, q.x, ta), g.y * s + fmaf(tb, q.y, ta),
-                                                            g.z * s + fmaf(tb, q.z, ta), g.w * s + fmaf(tb, q.w, ta));
-          else
-            reinterpret_cast<float4*>(gx)[at] = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+          float4 o = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+          if (tap_coef) o = make_float4(o.x + fmaf(tb, q.x, ta), o.y + fmaf(tb, q.y, ta), o.z + fmaf(tb, q.z, ta), o.w + fmaf(tb, q.w, ta));
+          if (add_in) {  // the other gradient of this BatchNorm input (from the derivative of this very backward): autograd's add, in here
+            const float4 e = reinterpret_cast<const float4*>(add_in)[at];
+            o = make_float4(o.x + e.x, o.y + e.y, o.z + e.z, o.w + e.w);
+          }
+          reinterpret_cast<float4*>(gx)[at] = o;
         }
         a0 += (g.x + g.y) + (g.z + g.w);
         a1 = fmaf(g.x, q.x, a1);
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
         const float q = x[at];
         if (ymask && !(ymask[at] > 0.f)) g = 0.f;
         if (gres) gres[at] = g;
-        if (gx) gx[at] = tap_coef ? g * s + fmaf(tb, q, ta) : g * s;
+        if (gx) gx[at] = (tap_coef ? g * s + fmaf(tb, q, ta) : g * s) + (add_in ? add_in[at] : 0.f);
         a0 += g;
         a1 = fmaf(g, q, a1);
         cnt += 1;
@@ -371,18 +374,18 @@ int bh_bn_eval_fwd(const float* x, const float* weight, const float* bias, const
 
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
                    float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, const float* y_mask,
-                   float* g_residual, int32_t B, int32_t C, int32_t HW, void* stream) {
+                   float* g_residual, const float* gx_add, int32_t B, int32_t C, int32_t HW, void* stream) {
   if (!eval_bn_args_ok(x, inv_std, mean_inv, B, C, HW) || gy == nullptr) return BH_EINVAL;
-  if ((reinterpret_cast<uintptr_t>(tap_coef) & 7u) != 0 || (tap_coef != nullptr && gx == nullptr)) return BH_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(tap_coef) & 7u) != 0 || ((tap_coef != nullptr || gx_add != nullptr) && gx == nullptr)) return BH_EINVAL;
   if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(gx) |
-                         reinterpret_cast<uintptr_t>(y_mask) | reinterpret_cast<uintptr_t>(g_residual)) & 15u) != 0)
+                         reinterpret_cast<uintptr_t>(y_mask) | reinterpret_cast<uintptr_t>(g_residual) | reinterpret_cast<uintptr_t>(gx_add)) & 15u) != 0)
     return BH_EINVAL;
   int S = 1, narrow = 0;
   const int grid = eval_bn_grid(B, C, HW, S, narrow);
   if (S > 1 && workspace == nullptr) return BH_EINVAL;
   hipStream_t st = bh::as_stream(stream);
   hipLaunchKernelGGL(bn_eval_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, gy, x, weight, inv_std, mean_inv, gx, gw, gb, workspace,
-                     tap_coef, tap_gout, y_mask, g_residual, B, C, HW, S, narrow);
+                     tap_coef, tap_gout, y_mask, g_residual, gx_add, B, C, HW, S, narrow);
   if (S > 1 && (gw != nullptr || gb != nullptr))
     hipLaunchKernelGGL(bn_eval_combine_kernel<2>, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, st, workspace, inv_std,
                        mean_inv, gw, gb, C, S);

@@ -275,10 +275,12 @@ int32_t bh_bn_eval_slabs(int32_t B, int32_t C, int32_t HW);
  * here anyway, so the prior's backward costs no traffic on models whose BatchNorm runs through these kernels.
  * reference: deepinversion.py:93-103 (the statistic whose gradient this is; math only).
  * `y_mask` (may be NULL): the forward OUTPUT of a launch with relu = 1; the incoming gradient is then masked first, gz = gy * [y > 0],
- * and gz takes gy's place everywhere (gx, gw, gb).  `g_residual` (may be NULL): receives gz, the gradient of the residual input. */
+ * and gz takes gy's place everywhere (gx, gw, gb).  `g_residual` (may be NULL): receives gz, the gradient of the residual input.
+ * `gx_add` (may be NULL, [B,C,HW]): added to gx -- the OTHER gradient of the same BatchNorm input in the attack's outer pass (d_x of
+ * bh_bn_eval_bwd_bwd), so that the framework's accumulation of the two needs no launch of its own. */
 int bh_bn_eval_bwd(const float* gy, const float* x, const float* weight, const float* inv_std, const float* mean_inv, float* gx,
                    float* gw, float* gb, double* workspace, const float* tap_coef, const float* tap_gout, const float* y_mask,
-                   float* g_residual, int32_t B, int32_t C, int32_t HW, void* stream);
+                   float* g_residual, const float* gx_add, int32_t B, int32_t C, int32_t HW, void* stream);
 /* Derivative of bh_bn_eval_bwd for incoming (ggx [B,C,HW], ggw [C], ggb [C]; each may be NULL = zero):
  * d_gy = ggx * s_c + ggw_c * (inv_std_c * x - mean_inv_c) + ggb_c;  d_x = ggw_c * inv_std_c * gy;  d_w_c = inv_std_c * sum(ggx * gy).
  * Outputs may be NULL (not computed).  With `y_mask` (the same forward output given to bh_bn_eval_bwd) and `gg_residual` (incoming

@@ -129,7 +129,7 @@ def main():
         y = x
         with torch.no_grad():
             for _ in range(n):
-                y = _EvalBNFunction.apply(y, wt, bs, inv, mi, None)
+                y = _EvalBNFunction.apply(y, wt, bs, inv, mi, None)[0]
         return y
 
     time_chain("kernel E forward at 1x64x56x56", bn, N, R, device)

@@ -40,7 +40,7 @@ if args.size.startswith("bneval"):
     for _ in range(args.reps):
         for a, gy, gx, gw, gb, ws, coef, inv, mi, m, B, C, hw in work:
             _lib.check(lib.bh_bn_eval_bwd(_lib.ptr(gy), _lib.ptr(a), _lib.ptr(m.weight), _lib.ptr(inv), _lib.ptr(mi), _lib.ptr(gx), _lib.ptr(gw),
-                                          _lib.ptr(gb), _lib.ptr(ws), _lib.ptr(coef if tap else None), _lib.ptr(gout if tap else None), None, None,
+                                          _lib.ptr(gb), _lib.ptr(ws), _lib.ptr(coef if tap else None), _lib.ptr(gout if tap else None), None, None, None,
                                           B, C, hw, st), "bn_eval_bwd")
     torch.cuda.synchronize()
     print(args.size, sum(a.numel() for a in acts), "elements per pass over the 53 BatchNorm inputs of ResNet-50 at B = 8")

@@ -291,11 +291,12 @@ def test_model_kernels_reject_bad_arguments_before_launching(hip_lib):
     assert hip_lib.bh_bn_eval_fwd(ok + 4, None, None, ok, ok, ok, None, None, 0, 1, 4, 16, None) == -1        # misaligned for 16-byte access
     assert hip_lib.bh_bn_eval_fwd(ok, None, None, ok, ok, ok, None, ok + 4, 1, 1, 4, 16, None) == -1          # misaligned residual
     assert hip_lib.bh_bn_eval_fwd(ok, None, None, ok, ok, ok, None, None, 2, 1, 4, 16, None) == -1            # relu is 0 / 1
-    assert hip_lib.bh_bn_eval_bwd(None, ok, None, ok, ok, ok, ok, ok, None, None, None, None, None, 1, 4, 16, None) == -1    # gy missing
-    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, None, None, None, None, 8, 4, 112 * 112, None) == -1  # S > 1 needs a workspace
-    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, ok + 4, None, None, None, 1, 4, 16, None) == -1   # tap pairs 8-byte aligned
-    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, None, ok, ok, None, ok, None, None, None, 1, 4, 16, None) == -1     # tap needs gx
-    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, None, None, ok + 4, None, 1, 4, 16, None) == -1   # misaligned mask
+    assert hip_lib.bh_bn_eval_bwd(None, ok, None, ok, ok, ok, ok, ok, None, None, None, None, None, None, 1, 4, 16, None) == -1    # gy missing
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, None, None, None, None, None, 8, 4, 112 * 112, None) == -1  # S > 1 needs a workspace
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, ok + 4, None, None, None, None, 1, 4, 16, None) == -1   # tap pairs 8-byte aligned
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, None, ok, ok, None, ok, None, None, None, None, 1, 4, 16, None) == -1     # tap needs gx
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, ok, ok, ok, None, None, None, ok + 4, None, None, 1, 4, 16, None) == -1   # misaligned mask
+    assert hip_lib.bh_bn_eval_bwd(ok, ok, None, ok, ok, None, ok, ok, None, None, None, None, None, ok, 1, 4, 16, None) == -1     # gx_add needs gx
     assert hip_lib.bh_bn_sums(1, None, None, ok, ok, 1, ok, 0, 3, None) == -1                                  # load depth 4 / 8 / 0
     assert hip_lib.bh_bn_finalize(1, ok, ok, ok, ok, ok, ok, ok, ok, 128, None) == -1                          # block 256 / 512 / 1024 / 0
     assert hip_lib.bh_bn_eval_bwd_bwd(None, None, None, None, ok, None, ok, ok, ok, ok, None, None, None, None, 1, 4, 16, None) == -1

@@ -912,7 +912,7 @@ def test_bn_eval_bwd_tap_arguments_against_numpy(hip_lib):
             ws = torch.empty(2 * C * S, dtype=torch.float64, device=_dev())
             _lib.check(hip_lib.bh_bn_eval_bwd(_lib.ptr(t["gy"]), _lib.ptr(t["x"]), _lib.ptr(t["w"]), _lib.ptr(t["inv"]), _lib.ptr(t["mi"]),
                                               _lib.ptr(gx), _lib.ptr(gw), _lib.ptr(gb), _lib.ptr(ws), _lib.ptr(t["coef"] if tap else None),
-                                              _lib.ptr(g if tap else None), None, None, B, C, HW, _lib.current_stream_handle(_dev())), "bwd")
+                                              _lib.ptr(g if tap else None), None, None, None, B, C, HW, _lib.current_stream_handle(_dev())), "bwd")
             out[tap] = [v.cpu().numpy().astype(np.float64) for v in (gx, gw, gb)]
         s = (w.astype(np.float64) * inv)[None, :, None, None]
         plain = host["gy"].astype(np.float64) * s
