@@ -122,7 +122,8 @@ def build():
     # --- gap census
     rows = []
     for tag, label in (("r4_1trial_gap_census.json", "round-3 form (BatchNorm, ReLU, residual add separate)"),
-                       ("r4_1trial_fused_gap_census.json", "BatchNorm + residual + ReLU in kernel E (default)"),
+                       ("r4_1trial_fused_gap_census.json", "BatchNorm + residual + ReLU in kernel E"),
+                       ("r4_1trial_head_gap_census.json", "... and the second gradient of each BatchNorm input folded into the launch (HEAD, default)"),
                        ("r4_1trial_gemm0_gap_census.json", "MIOPEN_DEBUG_CONV_GEMM=0")):
         c = _json_line(tag)
         if c and c.get("per_queue"):
