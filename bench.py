@@ -205,6 +205,8 @@ def parse_args():
                    help="timed CPU iterations of the reference (or its port), ~10 s of host work (0 disables)")
     p.add_argument("--cpu-threads", type=int, default=0,
                    help="threads of the CPU baseline (0 = min(os.cpu_count(), 16): the measured optimum, profiles/r4_cpu_thread_sweep.json)")
+    p.add_argument("--gm-cache-policy", default=None, metavar="FWD[,BWD]",
+                   help="force kernel A's cache policy (0 auto / 1 plain / 2 non-temporal loads / 3 + non-temporal stores), forward[,backward]")
     p.add_argument("--no-hbm-resident", action="store_true", help="skip the BERT-base sized kernel-A timing (roofline.hbm_resident)")
     p.add_argument("--model", default="resnet18")
     p.add_argument("--no-kernel-timing", action="store_true")
@@ -284,7 +286,11 @@ def main():
     torch.manual_seed(0)
     case = build_case(args.model, "ImageNet", 1, device=device, gradient_device=device)
     # hip_graph=required: a failed capture must fail the bench, not time eager launches under the graph's name
-    cfg = breaching_amd.get_attack_config("invertinggradients", [f"restarts.num_trials={world}", "impl.hip_graph=" + ("False" if args.no_graph else "required")])
+    overrides = [f"restarts.num_trials={world}", "impl.hip_graph=" + ("False" if args.no_graph else "required")]
+    if args.gm_cache_policy:
+        parts = args.gm_cache_policy.split(",")
+        overrides += [f"impl.gm_cache_policy={int(parts[0])}", f"impl.gm_cache_policy_bwd={int(parts[-1])}"]
+    cfg = breaching_amd.get_attack_config("invertinggradients", overrides)
     setup = dict(device=device, dtype=torch.float)
     attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, setup)
     rec_models, labels, stats = attacker.prepare_attack(case.server_payload, case.shared_data)

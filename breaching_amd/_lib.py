@@ -24,6 +24,7 @@ BH_BN_TILE = 4096
 BH_PRIOR_PARTIAL_STRIDE = 2
 BH_STATE_WORDS = 16
 BH_SCHED_STRIDE = 4
+GM_CACHE_AUTO, GM_CACHE_KEEP, GM_CACHE_STREAM, GM_CACHE_STREAM_ALL = 0, 1, 2, 3
 
 GM_KINDS = {
     "cosine-similarity": 0,
@@ -88,7 +89,7 @@ _PROTOTYPES = {
     "bh_gm_fwd": (
         c_int,
         [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_float, c_void_p,
-         c_int32, c_void_p, c_void_p, c_void_p],
+         c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     ),
     "bh_gm_fwd_rows": (c_int32, [c_int32, POINTER(c_int32), c_int32]),
     "bh_gm_finalize": (
@@ -98,8 +99,8 @@ _PROTOTYPES = {
     "bh_wall_clock_khz": (c_int32, []),
     "bh_gm_bwd": (
         c_int,
-        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_void_p],
+        [c_int32, c_int32, POINTER(c_void_p), c_void_p, c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+         c_void_p, c_void_p, c_void_p],
     ),
     "bh_gm_pack": (c_int, [c_int32, POINTER(c_void_p), c_void_p, c_int64, POINTER(c_int32), c_void_p, c_void_p]),
     "bh_prior_tv_norm": (

@@ -31,6 +31,25 @@ struct GmPtrs {
 };
 
 constexpr int kVecPerThread = BH_GM_CHUNK / 4 / kBlock;  // float4 loads per thread per operand for a full chunk
+
+// Cache policy of kernel A's streaming accesses (round 4, profiles/r4_nt_loads_probe.jsonl).  Both lists are read exactly once
+// per launch, so nothing is gained by keeping their lines -- and in the attack loop the forward runs right behind a producer
+// (autograd, or our own backward) whose dirty lines are still draining from L2 / the Infinity Cache: with plain loads the
+// BERT-base forward (688.6 MB) takes 131.5 us behind a writer against 106.7 us alone; with non-temporal loads
+// (`global_load_dwordx4 ... nt`) 94.6 us behind the same writer = 0.91 of the 8 TB/s peak (0.65 before).  A list that fits the
+// 256 MiB Infinity Cache wants the opposite: the backward re-reads what the forward pulled in (ResNet-18: forward 15.2 vs 15.6 us
+// but backward 22.3 vs 21.2 us with non-temporal forward loads).  Hence a per-launch policy, chosen by size unless the caller says
+// otherwise: BH_GM_CACHE_AUTO / _KEEP / _STREAM / _STREAM_ALL (include/breach_hip.h; the AUTO rule is at resolve_cache_policy).
+typedef float bh_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 stream_load(const float4* p) {
+  if constexpr (NT) {
+    const bh_v4f v = __builtin_nontemporal_load(reinterpret_cast<const bh_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *p;
+  }
+}
 static_assert(BH_GM_CHUNK % (4 * kBlock) == 0, "chunk must be a whole number of float4 sweeps");
 
 constexpr bool is_cosine_family(int kind) { return kind <= BH_GM_ANGULAR; }
@@ -194,7 +213,7 @@ __device__ void gm_combine_rows(int kind, const double* __restrict__ partials, i
 // before the current chunk is summed (mode 2).  ResNet-18 16.2 / 16.0 / 16.8 us, ResNet-50 31.1 / 31.1 / 32.6 us, BERT-base
 // 111 / 110 / 115 us for modes 0 / 1 / 2: the eight waves per CU already overlap each other's descriptor and data latency, the
 // extra registers of mode 2 (112 VGPRs) buy nothing.  The plain loop stays.
-template <int KIND>
+template <int KIND, bool NT>
 __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
                                                         const bh_gm_chunk* __restrict__ chunks, int chunk_begin,
                                                         int chunk_end, const float* __restrict__ weights, float tag_scale,
@@ -215,9 +234,9 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
     if (ch.len == BH_GM_CHUNK) {
       float4 rv[kVecPerThread], dv[kVecPerThread];
 #pragma unroll
-      for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
+      for (int k = 0; k < kVecPerThread; ++k) rv[k] = stream_load<NT>(r4 + tid + k * kBlock);
 #pragma unroll
-      for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
+      for (int k = 0; k < kVecPerThread; ++k) dv[k] = stream_load<NT>(d4 + tid + k * kBlock);
 #pragma unroll
       for (int k = 0; k < kVecPerThread; k += 2) {
         accumulate4<KIND>(rv[k], dv[k], a0, a1, a2);
@@ -225,7 +244,7 @@ __global__ __launch_bounds__(kBlock) void gm_fwd_kernel(GmPtrs ptrs, int tensor_
       }
     } else {
       const int n4 = ch.len >> 2;
-      for (int i = tid; i < n4; i += kBlock) accumulate4<KIND>(r4[i], d4[i], a0, a1, a2);
+      for (int i = tid; i < n4; i += kBlock) accumulate4<KIND>(stream_load<NT>(r4 + i), stream_load<NT>(d4 + i), a0, a1, a2);
       const int tail = ch.len & 3;
       if (tid < tail) accumulate<KIND>(r[(n4 << 2) + tid], d[(n4 << 2) + tid], b0, b1, b2);
     }
@@ -279,7 +298,18 @@ __device__ __forceinline__ float4 bwd_elem4(const float4& r, const float4& d, fl
                      bwd_elem<KIND>(r.z, d.z, k1, k2), bwd_elem<KIND>(r.w, d.w, k1, k2));
 }
 
-template <int KIND>
+template <bool NT>
+__device__ __forceinline__ void stream_store(float4* p, const float4& v) {
+  if constexpr (NT) {
+    bh_v4f w;
+    w.x = v.x, w.y = v.y, w.z = v.z, w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<bh_v4f*>(p));
+  } else {
+    *p = v;
+  }
+}
+
+template <int KIND, bool NTL, bool NTS>
 __global__ __launch_bounds__(kBlock) void gm_bwd_kernel(GmPtrs ptrs, int tensor_base, const float* __restrict__ data_flat,
                                                         const bh_gm_chunk* __restrict__ chunks, int chunk_base,
                                                         const float* __restrict__ weights,
@@ -301,14 +331,14 @@ __global__ __launch_bounds__(kBlock) void gm_bwd_kernel(GmPtrs ptrs, int tensor_
   if (ch.len == BH_GM_CHUNK) {
     float4 rv[kVecPerThread], dv[kVecPerThread];
 #pragma unroll
-    for (int k = 0; k < kVecPerThread; ++k) rv[k] = r4[tid + k * kBlock];
+    for (int k = 0; k < kVecPerThread; ++k) rv[k] = stream_load<NTL>(r4 + tid + k * kBlock);
 #pragma unroll
-    for (int k = 0; k < kVecPerThread; ++k) dv[k] = d4[tid + k * kBlock];
+    for (int k = 0; k < kVecPerThread; ++k) dv[k] = stream_load<NTL>(d4 + tid + k * kBlock);
 #pragma unroll
-    for (int k = 0; k < kVecPerThread; ++k) o4[tid + k * kBlock] = bwd_elem4<KIND>(rv[k], dv[k], k1, k2);
+    for (int k = 0; k < kVecPerThread; ++k) stream_store<NTS>(o4 + tid + k * kBlock, bwd_elem4<KIND>(rv[k], dv[k], k1, k2));
   } else {
     const int n4 = ch.len >> 2;
-    for (int i = tid; i < n4; i += kBlock) o4[i] = bwd_elem4<KIND>(r4[i], d4[i], k1, k2);
+    for (int i = tid; i < n4; i += kBlock) stream_store<NTS>(o4 + i, bwd_elem4<KIND>(stream_load<NTL>(r4 + i), stream_load<NTL>(d4 + i), k1, k2));
     const int tail = ch.len & 3;
     if (tid < tail) {
       const int i = (n4 << 2) + tid;
@@ -360,28 +390,59 @@ struct LaunchEvents {
   hipEvent_t start = nullptr, stop = nullptr;
 };
 
-template <int KIND>
-void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_begin,
-                int chunk_end, int grid, const float* weights, float tag_scale, double* partials, int row_base,
-                hipStream_t st, LaunchEvents ev) {
+template <int KIND, bool NT>
+void launch_fwd_policy(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_begin,
+                       int chunk_end, int grid, const float* weights, float tag_scale, double* partials, int row_base,
+                       hipStream_t st, LaunchEvents ev) {
   if (ev.start || ev.stop)
-    hipExtLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
+    hipExtLaunchKernelGGL((gm_fwd_kernel<KIND, NT>), dim3(grid), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
                           data_flat, chunks, chunk_begin, chunk_end, weights, tag_scale, partials, row_base);
   else
-    hipLaunchKernelGGL(gm_fwd_kernel<KIND>, dim3(grid), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+    hipLaunchKernelGGL((gm_fwd_kernel<KIND, NT>), dim3(grid), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
                        chunk_begin, chunk_end, weights, tag_scale, partials, row_base);
 }
 
 template <int KIND>
-void launch_bwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
-                int n, const float* weights, const float* stats, const float* gout, float* grad_flat, hipStream_t st,
-                LaunchEvents ev) {
+void launch_fwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_begin,
+                int chunk_end, int grid, const float* weights, float tag_scale, double* partials, int row_base,
+                hipStream_t st, LaunchEvents ev, bool stream) {
+  if (stream) launch_fwd_policy<KIND, true>(ptrs, tensor_base, data_flat, chunks, chunk_begin, chunk_end, grid, weights, tag_scale, partials, row_base, st, ev);
+  else launch_fwd_policy<KIND, false>(ptrs, tensor_base, data_flat, chunks, chunk_begin, chunk_end, grid, weights, tag_scale, partials, row_base, st, ev);
+}
+
+template <int KIND, bool NTL, bool NTS>
+void launch_bwd_policy(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
+                       int n, const float* weights, const float* stats, const float* gout, float* grad_flat, hipStream_t st,
+                       LaunchEvents ev) {
   if (ev.start || ev.stop)
-    hipExtLaunchKernelGGL(gm_bwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
+    hipExtLaunchKernelGGL((gm_bwd_kernel<KIND, NTL, NTS>), dim3(n), dim3(kBlock), 0, st, ev.start, ev.stop, 0, ptrs, tensor_base,
                           data_flat, chunks, chunk_base, weights, stats, gout, grad_flat);
   else
-    hipLaunchKernelGGL(gm_bwd_kernel<KIND>, dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
+    hipLaunchKernelGGL((gm_bwd_kernel<KIND, NTL, NTS>), dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, data_flat, chunks,
                        chunk_base, weights, stats, gout, grad_flat);
+}
+
+// policy: BH_GM_CACHE_KEEP plain accesses; BH_GM_CACHE_STREAM non-temporal loads; BH_GM_CACHE_STREAM_ALL non-temporal loads and stores
+template <int KIND>
+void launch_bwd(const GmPtrs& ptrs, int tensor_base, const float* data_flat, const bh_gm_chunk* chunks, int chunk_base,
+                int n, const float* weights, const float* stats, const float* gout, float* grad_flat, hipStream_t st,
+                LaunchEvents ev, int policy) {
+  if (policy == BH_GM_CACHE_STREAM_ALL) launch_bwd_policy<KIND, true, true>(ptrs, tensor_base, data_flat, chunks, chunk_base, n, weights, stats, gout, grad_flat, st, ev);
+  else if (policy == BH_GM_CACHE_STREAM) launch_bwd_policy<KIND, true, false>(ptrs, tensor_base, data_flat, chunks, chunk_base, n, weights, stats, gout, grad_flat, st, ev);
+  else launch_bwd_policy<KIND, false, false>(ptrs, tensor_base, data_flat, chunks, chunk_base, n, weights, stats, gout, grad_flat, st, ev);
+}
+
+// BH_GM_CACHE_AUTO, by the bytes the forward streams (two lists of n_chunks chunks of 4096 floats), measured INSIDE the attack loop
+// (profiles/r4_cache_policy_probe.jsonl, r4_cache_policy_inloop_resnet18.txt, r4_config3_cache_policy_{1,2}_kernel_summary.txt):
+//   ResNet-18 (93.5 MB): KEEP both -- non-temporal forward loads save 0.65 us there and cost the backward, which re-reads both lists
+//     out of the Infinity Cache, 1.5 us;
+//   ResNet-50 (204.5 MB): forward STREAM (43.0 -> 35.6 us behind the victim's double backward at B = 8), backward KEEP;
+//   BERT-base (688.6 MB): forward STREAM (131.9 -> 99.5 us behind a writer), backward STREAM_ALL (170.6 -> 163.2 us).
+int resolve_cache_policy(int32_t policy, int64_t n_chunks, bool backward) {
+  if (policy != BH_GM_CACHE_AUTO) return policy;
+  const int64_t forward_bytes = n_chunks * (int64_t)BH_GM_CHUNK * 8;
+  if (backward) return forward_bytes > BH_GM_CACHE_AUTO_BYTES ? BH_GM_CACHE_STREAM_ALL : BH_GM_CACHE_KEEP;
+  return forward_bytes > BH_GM_CACHE_AUTO_FWD_BYTES ? BH_GM_CACHE_STREAM : BH_GM_CACHE_KEEP;
 }
 
 // events of launch group g out of `groups`: start on the first non-empty group, stop on the last
@@ -475,9 +536,10 @@ int32_t bh_gm_fwd_rows(int32_t n_tensors, const int32_t* group_chunk_begin, int3
 
 int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, float tag_scale, double* partials_dev, int32_t rows_cap, void* stream,
-              void* ev_start, void* ev_stop) {
-  if (!rows_cap_ok(rows_cap)) return BH_EINVAL;
+              const float* weights_dev, float tag_scale, double* partials_dev, int32_t rows_cap, int32_t cache_policy,
+              void* stream, void* ev_start, void* ev_stop) {
+  if (!rows_cap_ok(rows_cap) || cache_policy < BH_GM_CACHE_AUTO || cache_policy > BH_GM_CACHE_STREAM_ALL) return BH_EINVAL;
+  const bool stream_loads = resolve_cache_policy(cache_policy, n_chunks, false) != BH_GM_CACHE_KEEP;
   if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
       n_chunks <= 0 || group_chunk_begin == nullptr || partials_dev == nullptr)
     return BH_EINVAL;
@@ -499,7 +561,7 @@ int bh_gm_fwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
     const int tb = g * BH_GM_MAX_PTRS;
     const LaunchEvents ev = group_events(ev_start, ev_stop, begin == 0, end == n_chunks);
 #define BH_FWD(K) \
-  launch_fwd<K>(ptrs, tb, data_flat, chunks_dev, begin, end, grid, weights_dev, tag_scale, partials_dev, row_base, st, ev)
+  launch_fwd<K>(ptrs, tb, data_flat, chunks_dev, begin, end, grid, weights_dev, tag_scale, partials_dev, row_base, st, ev, stream_loads)
     switch (kind) {
       case BH_GM_COSINE:
       case BH_GM_COSINE_FAST:
@@ -554,8 +616,10 @@ int32_t bh_wall_clock_khz(void) {
 
 int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, const float* data_flat,
               const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,
-              const float* weights_dev, const float* stats_dev, const float* gout_dev, float* grad_flat, void* stream,
-              void* ev_start, void* ev_stop) {
+              const float* weights_dev, const float* stats_dev, const float* gout_dev, float* grad_flat, int32_t cache_policy,
+              void* stream, void* ev_start, void* ev_stop) {
+  if (cache_policy < BH_GM_CACHE_AUTO || cache_policy > BH_GM_CACHE_STREAM_ALL) return BH_EINVAL;
+  const int policy = resolve_cache_policy(cache_policy, n_chunks, true);
   if (!valid_kind(kind) || n_tensors <= 0 || rec_ptrs == nullptr || !aligned16(data_flat) || chunks_dev == nullptr ||
       n_chunks <= 0 || group_chunk_begin == nullptr || stats_dev == nullptr || !aligned16(grad_flat))
     return BH_EINVAL;
@@ -578,22 +642,22 @@ int bh_gm_bwd(int32_t kind, int32_t n_tensors, const void* const* rec_ptrs, cons
       case BH_GM_COSINE_FAST:
       case BH_GM_ANGULAR:
         launch_bwd<BH_GM_COSINE>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat,
-                                 st, ev);
+                                 st, ev, policy);
         break;
       case BH_GM_COSINE_MASKED:
         launch_bwd<BH_GM_COSINE_MASKED>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev,
-                                        grad_flat, st, ev);
+                                        grad_flat, st, ev, policy);
         break;
       case BH_GM_L2:
       case BH_GM_PEARL_L2:  // same derivative as the euclidean objective
-        launch_bwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st, ev);
+        launch_bwd<BH_GM_L2>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st, ev, policy);
         break;
       case BH_GM_L1:
-        launch_bwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st, ev);
+        launch_bwd<BH_GM_L1>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat, st, ev, policy);
         break;
       default:
         launch_bwd<BH_GM_TAG>(ptrs, tb, data_flat, chunks_dev, begin, n, weights_dev, stats_dev, gout_dev, grad_flat,
-                              st, ev);
+                              st, ev, policy);
         break;
     }
     const int rc = bh::launch_status();

@@ -38,9 +38,13 @@ class GradientMatchPlan:
     dropped like ``zip`` does at objectives.py:190.
     """
 
-    def __init__(self, gradient_data, n_pairs=None, rows_cap=0):
+    def __init__(self, gradient_data, n_pairs=None, rows_cap=0, cache_policy=0, cache_policy_bwd=None):
         lib = _lib.load()
         self.rows_cap = int(rows_cap)  # workgroups per forward launch group (0 = BH_GM_DEFAULT_ROWS): a plan field, not library state
+        # cache policy of the streaming accesses (0 = by size: non-temporal loads when the two lists exceed the Infinity Cache;
+        # 1 plain; 2 non-temporal loads; 3 non-temporal loads and backward stores) -- _lib.GM_CACHE_*
+        self.cache_policy = int(cache_policy)                                                      # forward launch
+        self.cache_policy_bwd = int(cache_policy if cache_policy_bwd is None else cache_policy_bwd)  # backward launch
         tensors = list(gradient_data)
         if n_pairs is not None:
             tensors = tensors[:n_pairs]
@@ -192,7 +196,7 @@ class GradientMatchPlan:
         ev0, ev1 = self._timed("fwd")
         _lib.check(
             lib.bh_gm_fwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), self.rows_cap, stream, ev0, ev1),
+                          self._group_bounds, _lib.ptr(weights), float(tag_scale), _lib.ptr(partials), self.rows_cap, self.cache_policy, stream, ev0, ev1),
             "bh_gm_fwd",
         )
         ev0, ev1 = self._timed("fin")
@@ -212,7 +216,7 @@ class GradientMatchPlan:
         ev0, ev1 = self._timed("bwd")
         _lib.check(
             lib.bh_gm_bwd(kind, self.n_tensors, ptrs, _lib.ptr(self.data_flat), _lib.ptr(self.chunks_dev), self.n_chunks,
-                          self._group_bounds, _lib.ptr(weights), _lib.ptr(stats), _lib.ptr(gout), _lib.ptr(grad_flat), stream, ev0, ev1),
+                          self._group_bounds, _lib.ptr(weights), _lib.ptr(stats), _lib.ptr(gout), _lib.ptr(grad_flat), self.cache_policy_bwd, stream, ev0, ev1),
             "bh_gm_bwd",
         )
         return grad_flat
@@ -413,14 +417,14 @@ class HipGradientLoss(torch.nn.Module):
         for plan in self._plans:
             if plan.matches(gradient_data, n_pairs):
                 return plan
-        rows_cap = 0
+        tuning = dict(rows_cap=0, cache_policy=0, cache_policy_bwd=0)  # measurements only: cfg.impl.gm_rows_cap / gm_cache_policy[_bwd]
         impl = getattr(self, "cfg_impl", None)
-        if impl is not None:
+        for key in tuning:
             try:
-                rows_cap = int(impl["gm_rows_cap"] or 0)  # tuning (measurements only): workgroups per forward launch group
+                tuning[key] = int(impl[f"gm_{key}"] or 0)
             except (KeyError, AttributeError, TypeError):
-                rows_cap = 0
-        plan = GradientMatchPlan(gradient_data, n_pairs, rows_cap=rows_cap)
+                pass
+        plan = GradientMatchPlan(gradient_data, n_pairs, **tuning)
         self._plans.append(plan)  # one plan per observed list: multi-query / multi-model payloads alternate between them
         return plan
 

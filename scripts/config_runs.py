@@ -32,7 +32,8 @@ setup = dict(device=dev, dtype=torch.float)
 # kernel D tuning for same-box A/B profiles: since ABI 5 these are launch arguments carried by the plan (cfg.impl.bn_grid_cap /
 # bn_load_depth / bn_finalize_block), not process-wide library state
 BN_TUNING = [f"impl.{key}={os.environ[env]}" for env, key in (("BN_DEPTH", "bn_load_depth"), ("BN_GRID_CAP", "bn_grid_cap"),
-                                                               ("BN_FIN_BLOCK", "bn_finalize_block")) if env in os.environ]
+                                                               ("BN_FIN_BLOCK", "bn_finalize_block"), ("GM_CACHE", "gm_cache_policy"),
+                                                               ("GM_CACHE_BWD", "gm_cache_policy_bwd")) if env in os.environ]
 out = {}
 
 

@@ -85,7 +85,8 @@ def test_chunk_table_host_helpers(hip_lib):
     assert list(bounds) == [0, _lib.BH_GM_MAX_PTRS, len(many)]
     # invalid arguments are reported, not crashed on
     assert hip_lib.bh_gm_table_size(-1, arr, byref(n_chunks), byref(flat)) == -1
-    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, 0, None, None, None) == -1
+    assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, 0, 0, None, None, None) == -1
+    assert hip_lib.bh_gm_fwd(0, 1, None, None, None, 1, None, None, 0.0, None, 0, 7, None, None, None) == -1  # unknown cache policy
     assert hip_lib.bh_candidate_step(None, None, None, None, None, None, None, None, None, None, None) == -1
 
 
