@@ -610,6 +610,34 @@ def test_eval_batchnorm_function_matches_torch_through_two_orders(shape, affine,
         close(got[2][1], ref[2][1], "second order wrt weight")
 
 
+def test_gm_cache_policies_change_no_result(hip_lib):
+    """Kernel A's cache policy (plain accesses / non-temporal loads / non-temporal loads and backward stores; chosen by list size
+    unless forced) is a memory-system hint only: statistics and gradients are bit-identical under every policy, ragged tails and
+    the TAG weights included.  objectives.py:89-95, 133-141, 183-196 (the reductions behind it)."""
+    from breaching_amd import _lib
+    from breaching_amd.gm import GradientMatchPlan
+
+    rng = np.random.default_rng(9)
+    shapes = [(300_001,), (17,), (4096 * 5,), (70_003,), (5,), (64, 64, 3, 3)]
+    data = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
+    rec = [torch.tensor(rng.standard_normal(s).astype(np.float32), device=_dev()) for s in shapes]
+    w = torch.linspace(1.0, 0.1, len(shapes), device=_dev())
+    out = {}
+    for policy in (_lib.GM_CACHE_AUTO, _lib.GM_CACHE_KEEP, _lib.GM_CACHE_STREAM, _lib.GM_CACHE_STREAM_ALL):
+        plan = GradientMatchPlan(data, cache_policy=policy)
+        for kind in (0, 4, 6):
+            weights = w if kind == 6 else None
+            stats = plan.forward(kind, rec, 1.5, 0.1, 1e-7, weights)
+            grad = plan.backward(kind, rec, stats, None, weights)
+            out[(policy, kind)] = (stats[:6].clone(), grad.clone())
+    for kind in (0, 4, 6):
+        base = out[(_lib.GM_CACHE_KEEP, kind)]
+        for policy in (_lib.GM_CACHE_AUTO, _lib.GM_CACHE_STREAM, _lib.GM_CACHE_STREAM_ALL):
+            assert torch.equal(out[(policy, kind)][0], base[0]) and torch.equal(out[(policy, kind)][1], base[1]), (policy, kind)
+    with pytest.raises(Exception):
+        GradientMatchPlan(data, cache_policy=9).forward(0, rec, 1.0, 0.0, 1e-7, None)
+
+
 @pytest.mark.parametrize("relu,with_residual", [(True, False), (True, True), (False, True)])
 @pytest.mark.parametrize("shape", [(1, 64, 56, 56), (2, 12, 7, 7), (3, 5, 9, 11), (8, 16, 64, 64), (1, 512, 7, 7)])
 def test_eval_batchnorm_epilogue_matches_torch_through_two_orders(shape, relu, with_residual, hip_lib):
