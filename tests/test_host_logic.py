@@ -643,6 +643,25 @@ def test_design_tables_are_generated_from_the_committed_profiles():
         assert os.path.exists(os.path.join(root, "profiles", name)), name
 
 
+def test_bench_hbm_resident_list_is_bert_base_without_the_word_embedding():
+    """bench.py's `roofline.hbm_resident` leg times kernel A on a synthetic list with the shapes a TAG attack on BERT-base matches
+    (SURVEY.md section 8 size table: 201 of 202 tensors, 86 073 402 elements): checked against the real model's parameter list."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    shapes = bench.bert_base_gradient_shapes()
+    assert len(shapes) == 201 and sum(math.prod(s) for s in shapes) == 86_073_402
+    from breaching_amd.cases import build_text_case
+
+    case = build_text_case(device="cpu", full_size=True, seq_len=32)
+    real = [tuple(p.shape) for name, p in case.model.named_parameters() if "word_embeddings" not in name]
+    assert sorted(real) == sorted(shapes)
+
+
 def test_bench_cpu_baseline_is_the_unmodified_reference_when_a_checkout_is_importable(monkeypatch):
     """bench.py's `cpu_baseline` leg (no GPU needed): with the reference checkout present (this container) it times the
     UNMODIFIED reference (`kind: "reference"`); pointed at a directory without one (the GPU box) it times the port and reports
