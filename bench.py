@@ -285,8 +285,9 @@ def main():
     # ---- workload --------------------------------------------------------------------------------------------------
     torch.manual_seed(0)
     case = build_case(args.model, "ImageNet", 1, device=device, gradient_device=device)
-    # hip_graph=required: a failed capture must fail the bench, not time eager launches under the graph's name
-    overrides = [f"restarts.num_trials={world}", "impl.hip_graph=" + ("False" if args.no_graph else "required")]
+    # N = 1: a failed capture fails the bench.  N > 1 (a multi-rank run exists only on the driver's 8-GPU node and has never been
+    # rehearsed): fall back to eager launches instead of losing the whole scaling run -- `launch_mode` / `graph_capture_error` say so
+    overrides = [f"restarts.num_trials={world}", "impl.hip_graph=" + ("False" if args.no_graph else ("required" if world == 1 else "auto"))]
     if args.gm_cache_policy:
         parts = args.gm_cache_policy.split(",")
         overrides += [f"impl.gm_cache_policy={int(parts[0])}", f"impl.gm_cache_policy_bwd={int(parts[-1])}"]
