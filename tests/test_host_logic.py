@@ -685,3 +685,50 @@ def test_bench_cpu_baseline_is_the_unmodified_reference_when_a_checkout_is_impor
         assert leg["anchor"]["port_over_reference"] == pytest.approx(1.0, abs=0.1) and leg["anchor"]["file"].endswith("cpu_baseline_anchor.json")
     finally:
         torch.set_num_threads(threads)
+
+
+def test_gap_census_on_a_synthetic_trace(tmp_path):
+    """scripts/gap_census.py (the instrument behind DESIGN.md section 6's dispatch / gap tables) on a trace whose answer is known:
+    two queues, ten iterations of 50 dispatches each ending in a candidate step, 2 us kernels, 1 us gaps, one 40 us gap per
+    iteration behind an Im2Col."""
+    import csv
+    import importlib.util
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rows = []
+    for queue in ("1", "2"):
+        t = 1_000_000 + int(queue) * 300
+        for _ in range(10):
+            for k in range(50):
+                name = "candidate_step_kernel(Word)" if k == 49 else ("Im2d2Col_v2" if k == 10 else "void at::native::vectorized_elementwise_kernel<4, at::native::CUDAFunctor_add<float>>")
+                gap = 40_000 if k == 11 else 1_000
+                rows.append(dict(Kind="KERNEL_DISPATCH", Queue_Id=queue, Stream_Id=queue, Kernel_Name=name, Start_Timestamp=t + gap, End_Timestamp=t + gap + 2_000,
+                                 Grid_Size_X=256, Grid_Size_Y=1, Grid_Size_Z=1, Workgroup_Size_X=256, Workgroup_Size_Y=1, Workgroup_Size_Z=1, Scratch_Size=0))
+                t += gap + 2_000
+    trace = tmp_path / "1_kernel_trace.csv"
+    with open(trace, "w") as f:
+        writer = csv.DictWriter(f, fieldnames=list(rows[0]))
+        writer.writeheader()
+        writer.writerows(rows)
+    spec = importlib.util.spec_from_file_location("gap_census", os.path.join(root, "scripts", "gap_census.py"))
+    census = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(census)
+    import sys
+
+    argv, sys.argv = sys.argv, ["gap_census.py", str(trace), str(tmp_path / "out"), "--iters", "5"]
+    try:
+        census.main()
+    finally:
+        sys.argv = argv
+    result = json.load(open(tmp_path / "out.json"))
+    assert sorted(result["per_queue"]) == ["1", "2"]
+    q = result["per_queue"]["1"]
+    assert q["iterations"] == 5 and q["dispatches_per_iter"] == 50 and q["kernel_us_per_iter"] == 100.0
+    assert q["gap_us_per_iter"] == pytest.approx(49 * 1.0 + 40.0) and q["wall_us_per_iter"] == pytest.approx(189.0)
+    families = {f["family"]: f for f in q["families"]}
+    assert families["MIOpen: Im2Col / Col2Im"]["gap_after_us_per_iter"] == pytest.approx(40.0)  # the long gap is charged to its predecessor ...
+    assert families["ATen: add (accumulation, residual)"]["gap_before_us_per_iter"] == pytest.approx(40.0 + 47.0)  # ... and to its successor
+    assert families["ours: kernel B/C, commit (step, tv, loss)"]["calls_per_iter"] == 1.0
+    assert os.path.exists(tmp_path / "out_one_iteration.csv")
