@@ -1358,19 +1358,21 @@ def fast_layer_norm_enabled(cfg):
 
 def trials_in_flight(cfg):
     """How many of a rank's trials run concurrently on separate streams: cfg.impl.trials_in_flight or
-    BREACH_HIP_TRIALS_IN_FLIGHT, default 4, never more than MAX_TRIALS_IN_FLIGHT.  Measured on one MI355X, ResNet-18
-    (profiles/r3_inflight_width.jsonl and round 2): 191 / 320 / 403 / 474 iterations/s with 1 / 2 / 3 / 4 trials in flight,
-    then a collapse -- 215 with 6 and 215 with 8 (GPU_MAX_HW_QUEUES 8 or 16 alike): beyond four concurrently replaying graphs
-    the runtime serialises them.  1 restores the reference's strictly sequential order; per-trial results do not depend on
-    the width."""
+    BREACH_HIP_TRIALS_IN_FLIGHT, default 4, never more than MAX_TRIALS_IN_FLIGHT.  Measured on one MI355X, ResNet-18: 228 / 356 /
+    ~450 / 526-545 iterations/s with 1 / 2 / 3 / 4 trials in flight, then a collapse -- 216 / 248 / 277 with 5 / 6 / 8.  Round 4
+    found the reason (profiles/r4_inflight_pipes_probe.jsonl, breaching_amd/streams.py): streams are hardware queues dealt onto FOUR
+    compute pipes, and two graph-replaying streams on one pipe run slower than one after the other (two trials: 80 vs 356 it/s);
+    a fifth busy stream always shares a pipe.  Within the four, throughput is bounded by the chip-wide retirement rate of dependent
+    dispatches, not by CUs (profiles/r4_cu_mask_probe.jsonl).  1 restores the reference's strictly sequential order; per-trial
+    results do not depend on the width."""
     import os
 
     env = os.environ.get("BREACH_HIP_TRIALS_IN_FLIGHT")
     value = int(env) if env is not None else _cfg_get(cfg.impl, "trials_in_flight", DEFAULT_TRIALS_IN_FLIGHT)
     value = max(int(value or DEFAULT_TRIALS_IN_FLIGHT), 1)
     if value > MAX_TRIALS_IN_FLIGHT:
-        log.warning(f"trials_in_flight={value} lowered to {MAX_TRIALS_IN_FLIGHT}: more concurrent graph replays than that run "
-                    "slower than four on this platform (measured, see attacker.trials_in_flight).")
+        log.warning(f"trials_in_flight={value} lowered to {MAX_TRIALS_IN_FLIGHT}: the GPU has four hardware compute pipes, and a fifth "
+                    "graph-replaying stream shares one -- slower than four (measured, see attacker.trials_in_flight).")
         value = MAX_TRIALS_IN_FLIGHT
     return value
 
