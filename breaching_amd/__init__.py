@@ -10,8 +10,10 @@ import os as _os
 
 # Restarts in flight run on separate HIP streams (attacker._run_trial_group).  ROCclr multiplexes streams onto
 # GPU_MAX_HW_QUEUES hardware queues (default 4, one of which the caller's stream holds); with two trials sharing a queue
-# the four-in-flight rate drops from ~475 to ~310 iterations/s (measured).  Only a default, and only effective when set
-# before the HIP runtime initialises, i.e. before the first CUDA call of the process.
+# the four-in-flight rate drops from ~475 to ~310 iterations/s (measured in round 2).  Eight queues give every side stream
+# one of its own next to the caller's; the queues in turn sit on four hardware compute pipes, which is what
+# breaching_amd/streams.py picks the side streams by (round 4).  Only a default, and only effective when set before the HIP
+# runtime initialises, i.e. before the first CUDA call of the process.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .config import AttrDict, get_attack_config, get_data_config  # noqa: E402,F401
