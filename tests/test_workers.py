@@ -149,3 +149,43 @@ def test_each_rank_gets_its_own_miopen_user_db(monkeypatch, tmp_path):
     assert workers.isolate_miopen_user_db(5) == first  # already set in this process (by the call above): left alone
     monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
     assert workers.isolate_miopen_user_db(1) == "/somewhere/else"
+
+
+def test_eight_ranks_share_32_restarts_like_an_eight_gpu_node():
+    """BASELINE configs[3] in its multi-rank shape, on CPU over gloo: the caller + seven worker processes = eight ranks, 32 restarts,
+    rank r holds trials {t : t mod 8 = r} (four each).  One all-reduce(MIN) on the packed keys + one broadcast make every rank agree
+    on the winner; the 32 loss histories reach rank 0; NaN scores lose; a tie goes to the lower trial index (torch.min's choice in
+    the reference's sequential loop, optimization_based_attack.py:206-218).  The 8-rank rendezvous, the job protocol and the
+    selection have otherwise only run with 2-4 ranks."""
+    from breaching_amd import trials, workers
+    from breaching_amd.workers import TrialWorkerPool
+
+    num_trials = 32
+    pool = TrialWorkerPool([None] * 8, _runner_factory, (num_trials,))
+    try:
+        assert pool.world == 8 and pool.backend == "gloo"
+        rng = torch.Generator().manual_seed(0)
+        for round_ in range(2):
+            scores = (torch.rand(num_trials, generator=rng) + 0.5).tolist()
+            scores[5] = float("nan")
+            scores[29] = 0.125 if round_ == 0 else scores[29]  # a clear winner on the last rank's share ...
+            if round_ == 1:
+                scores[11] = scores[19] = 0.0625                # ... and a tie between trials of rank 3
+            pool.submit([dict(scores=scores)] * 7)
+            shard = trials.TrialShard.current(num_trials)
+            assert (shard.rank, shard.world) == (0, 8) and list(shard.local_trials()) == [0, 8, 16, 24]
+            solutions = {t: torch.full((2, 3), float(t)) for t in shard.local_trials()}
+            stats = {f"Trial_{t}_Val": [float(t)] * 3 for t in shard.local_trials()}
+            pool.expect("trials_done")
+            pool.broadcast(("go",))
+            value, solution = shard.select(solutions, {t: scores[t] for t in shard.local_trials()}, stats, torch.device("cpu"))
+            pool.finish()
+            want_trial = 29 if round_ == 0 else 11
+            assert value == pytest.approx(scores[want_trial]) and float(solution[0, 0]) == float(want_trial)
+            assert sorted(stats) == sorted(f"Trial_{t}_Val" for t in range(num_trials))
+            assert all(stats[f"Trial_{t}_Val"] == [float(t)] * 3 for t in range(num_trials))
+        described = pool.describe()
+        assert described["world"] == 8 and described["pool_start_s"] > 0 and described["job_ship_s"] >= 0
+    finally:
+        pool.close(force=True)
+    assert workers.active_pool() is None
