@@ -280,6 +280,48 @@ def test_restatement_resnet18_imagenet(golden_dir):
     _compare("", gold, rec, stats, case, crop=32)
 
 
+def test_restatement_at_the_reference_iterates_of_the_24k_run_value_and_step_direction(golden_dir):
+    """The CPU restatement (objective + total variation, oracle/restate.py) pinned to the UNMODIFIED reference's full-length run of
+    BASELINE configs[1] (tests/golden/attack_resnet18_24k.npz): at the reference's own iterates x_k -- early, right after the first
+    milestone and ten iterations before the end of the 24 000 -- its loss equals the reference's history[k] and the sign of its
+    input gradient equals the map the reference's closure left in `candidate.grad` after `sign_()`
+    (optimization_based_attack.py:152-165, 181-182); the raw gradient agrees with the recorded one to its bf16 storage precision.
+    This is the checker the GPU tests hold the HIP path to, validated here against the real thing."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import parameter_checksum
+    from oracle import restate
+
+    path = os.path.join(golden_dir, "attack_resnet18_24k.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/attack_resnet18_24k.npz not generated")
+    gold = np.load(path)
+    torch.set_num_threads(int(gold["threads"]))  # the reduction order of the fp32 sums follows the thread count
+    case = _cpu_case("resnet18", "ImageNet", 1)
+    assert parameter_checksum(case.model) == pytest.approx(float(gold["model_checksum"]), rel=1e-12)
+    cfg = get_attack_config("invertinggradients", [f"optim.max_iterations={int(gold['iterations'])}"])
+    labels = case.shared_data[0]["metadata"]["labels"]
+    tv = cfg.regularization["total_variation"]
+    assert int(gold["iterations"]) == 24000 and len(gold["history"]) == 24000
+    for i in (0, 3, 6):  # k = 100, 9100, 23991
+        k = int(gold["forced_k"][i])
+        x = torch.as_tensor(gold["forced_x"][i]).clone().requires_grad_(True)
+        loss = case.loss_fn(case.model(x), labels)
+        grads = torch.autograd.grad(loss, tuple(case.model.parameters()), create_graph=True)
+        total = restate.gradient_objective(cfg.objective.type, grads, case.shared_data[0]["gradients"], cfg.objective)
+        total = total + restate.total_variation(x, **tv)
+        (gx,) = torch.autograd.grad(total, x)
+        assert float(total.detach()) == pytest.approx(float(gold["history"][k]), rel=1e-5), k  # fp32 sums over 11.7 M terms
+        sign_ref = torch.as_tensor(gold["forced_sign"][i].astype(np.float32))
+        agreement = float((torch.sign(gx) == sign_ref).double().mean())
+        assert agreement >= 0.99999, (k, agreement)  # same arithmetic on the same CPU: the maps are the same map
+        recorded = torch.as_tensor((gold["forced_grad_bf16"][i].astype(np.uint32) << 16).view(np.float32))
+        rel = float((gx - recorded).norm() / recorded.norm())
+        assert rel <= 5e-3, (k, rel)  # bf16 by truncation: up to 2^-8 per element, 0.28 % on the norm
+    # the three full-length runs are what the fixture says they are
+    assert gold["twin_history"].shape == (2, 24000) and gold["history"][-1] < gold["history"][0] / 5
+    assert (gold["forced_twin_sign_agreement"] > 0.97).all() and (gold["forced_twin_sign_agreement"] < 1.0).all()
+
+
 def test_restatement_resnet50_seethrough_with_langevin_noise(golden_dir):
     from breaching_amd import get_attack_config
     from breaching_amd.cases import initial_candidate
