@@ -307,3 +307,30 @@ def test_model_kernels_reject_bad_arguments_before_launching(hip_lib):
     assert hip_lib.bh_ln_bwd_bwd(ok, None, None, ok, ok, None, ok, ok, ok, ok, ok, None, 4, 8, None) == -1  # d_gamma needs row scalars
     assert hip_lib.bh_bn_bwd_accumulate(None, None, 16, ok, ok, 1, ok, None, ok, None) == -1
     assert hip_lib.bh_bn_bwd_accumulate(ok, None, 16, ok, ok, 0, ok, None, ok, None) == -1
+
+
+def test_static_kernel_resources_no_scratch_and_full_occupancy_for_the_streaming_kernels():
+    """hipcc's own resource report for gfx950 (scripts/kernel_resources.py, no GPU): no kernel of the library uses scratch memory or
+    spills vector registers, and every HBM-streaming kernel (A, D's sums / backward, E, F, mt) stays within 64 VGPRs, i.e. the
+    eight waves per SIMD that DESIGN.md section 3 prices their latency hiding on.  The committed table is the one this produces."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    rows = kernel_resources.collect()
+    assert len(rows) >= 60 and all("kernel" in r for r in rows)
+    for r in rows:
+        assert r["scratch"] == 0 and r["vgpr_spill"] == 0 and r["agpr"] == 0, r
+    streaming = [r for r in rows if re.match(r"(gm_fwd|gm_bwd|bn_sums|bn_bwd|bn_eval_(fwd|bwd)|ln_|mt_kernel)", r["kernel"])]
+    assert len(streaming) >= 40
+    for r in streaming:
+        assert r["vgpr"] <= 64 and r["waves"] == 8, r
+    exceptions = sorted({r["kernel"].split("<")[0] for r in rows if r["waves"] < 8})
+    assert exceptions == ["bn_finalize_kernel", "tv_norm_kernel"], exceptions  # small, latency-bound: DESIGN.md names them
+    with open(os.path.join(root, "profiles", "r4_kernel_resources.txt")) as f:
+        committed = f.read()
+    assert committed == kernel_resources.render(rows), "profiles/r4_kernel_resources.txt is stale: python scripts/kernel_resources.py --out ..."
