@@ -2,7 +2,7 @@
 
     python scripts/config_runs.py [--full]        # --full: the real 24 000-iteration ResNet-18 run of configs[1]
 """
-import argparse, json, logging, os, sys, time
+import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import breaching_amd

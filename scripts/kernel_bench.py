@@ -5,13 +5,13 @@
 Kernel A is timed with hipExtLaunchKernelGGL start/stop events (same as bench.py); the other kernels with an event pair
 around a burst of back-to-back launches on the stream (burst average, includes the ~1.5 us kernel boundary).
 """
-import ctypes, json, os, sys
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from breaching_amd import _lib, schedules
 from breaching_amd.cases import ResNet, build_text_case
 from breaching_amd.gm import GradientMatchPlan
-from breaching_amd.priors import launch_tv_norm, ctypes_offset
+from breaching_amd.priors import launch_tv_norm
 
 dev = torch.device("cuda:0")
 lib = _lib.load()

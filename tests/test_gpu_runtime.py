@@ -37,7 +37,6 @@ def test_capture_failure_falls_back_visibly_and_raises_when_required(monkeypatch
     stats["execution"] (the reference attacks arbitrary models; one that cannot be captured must not crash the attack);
     "required" (this suite's and bench.py's mode): it raises; False: never captured."""
     import breaching_amd
-    from breaching_amd import attacker as attacker_module
     from breaching_amd.cases import build_case, initial_candidate
 
     case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
