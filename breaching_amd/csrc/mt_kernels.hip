@@ -51,6 +51,50 @@ __device__ __forceinline__ float4 mt_elem4(const float4& a, const float4& b, con
                      mt_elem<OP>(a.w, b.w, c.w, k0, k1));
 }
 
+// One chunk, one workgroup.  Every thread issues all of its 16-byte loads (BH_GM_CHUNK / 4 / kBlock per list = 4) before
+// the first use, then computes and stores: 12 loads in flight per thread for the three-operand forms.  HAS_A is resolved
+// per workgroup by the caller -- with the null test inside the loop (`a4 ? a4[i] : zero`, rounds 2-3) the compiler
+// scalarised the float4 into four branch-guarded dword loads per operand (profiles/r4_kernel_isa_census.txt).
+constexpr int kMtIters = BH_GM_CHUNK / 4 / kBlock;
+static_assert(kMtIters * 4 * kBlock == BH_GM_CHUNK, "a chunk is a whole number of 16-byte accesses per thread");
+
+template <int OP, bool HAS_A>
+__device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                         float* __restrict__ o, int len, float k0, float k1) {
+  constexpr bool needs_b = OP != kScale, needs_c = OP == kAxpyMinus || OP == kPatch;
+  const int tid = threadIdx.x;
+  const int n4 = len >> 2;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* __restrict__ a4 = reinterpret_cast<const float4*>(a);
+  const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b);
+  const float4* __restrict__ c4 = reinterpret_cast<const float4*>(c);
+  float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
+  float4 av[kMtIters], bv[kMtIters], cv[kMtIters];
+#pragma unroll
+  for (int j = 0; j < kMtIters; ++j) {
+    const int i = tid + j * kBlock;
+    av[j] = bv[j] = cv[j] = zero;
+    if (i < n4) {
+      if constexpr (HAS_A) av[j] = a4[i];
+      if constexpr (needs_b) bv[j] = b4[i];
+      if constexpr (needs_c) cv[j] = c4[i];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kMtIters; ++j) {
+    const int i = tid + j * kBlock;
+    if (i < n4) o4[i] = mt_elem4<OP>(av[j], bv[j], cv[j], k0, k1);
+  }
+  const int tail = len & 3;
+  if (tid < tail) {
+    const int i = (n4 << 2) + tid;
+    const float a_i = HAS_A ? a[i] : 0.f;
+    const float b_i = needs_b ? b[i] : 0.f;
+    const float c_i = needs_c ? c[i] : 0.f;
+    o[i] = mt_elem<OP>(a_i, b_i, c_i, k0, k1);
+  }
+}
+
 // One workgroup per chunk.  `c_flat`: the third operand comes from a packed buffer (patch) instead of a pointer list.
 // `coef`: device pair overriding (k0, k1) when non-NULL (patch).  A NULL `a` pointer reads as zeros (scale of a missing
 // upstream gradient).
@@ -68,25 +112,13 @@ __global__ __launch_bounds__(kBlock) void mt_kernel(MtPtrs ptrs, int tensor_base
     k1 = k0 * coef[1];
     k0 = k0 * coef[0];
   }
-  const int tid = threadIdx.x;
-  const int n4 = ch.len >> 2;
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr bool needs_b = OP != kScale, needs_c = OP == kAxpyMinus || OP == kPatch;
-  const float4* __restrict__ a4 = a ? reinterpret_cast<const float4*>(a + ch.tensor_off) : nullptr;
-  const float4* __restrict__ b4 = needs_b ? reinterpret_cast<const float4*>(b + ch.tensor_off) : nullptr;
-  const float4* __restrict__ c4 =
-      needs_c ? reinterpret_cast<const float4*>(c_flat ? c : c + ch.tensor_off) : nullptr;
-  float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
-  for (int i = tid; i < n4; i += kBlock)
-    o4[i] = mt_elem4<OP>(a4 ? a4[i] : zero, needs_b ? b4[i] : zero, needs_c ? c4[i] : zero, k0, k1);
-  const int tail = ch.len & 3;
-  if (tid < tail) {
-    const int i = (n4 << 2) + tid;
-    const float av = a ? a[ch.tensor_off + i] : 0.f;
-    const float bv = needs_b ? b[ch.tensor_off + i] : 0.f;
-    const float cv = needs_c ? (c_flat ? c[i] : c[ch.tensor_off + i]) : 0.f;
-    o[i] = mt_elem<OP>(av, bv, cv, k0, k1);
-  }
+  const float* __restrict__ bp = needs_b ? b + ch.tensor_off : nullptr;
+  const float* __restrict__ cp = needs_c ? (c_flat ? c : c + ch.tensor_off) : nullptr;
+  if (a)  // uniform over the workgroup
+    mt_chunk<OP, true>(a + ch.tensor_off, bp, cp, o, ch.len, k0, k1);
+  else
+    mt_chunk<OP, false>(nullptr, bp, cp, o, ch.len, k0, k1);
 }
 
 bool ok_ptr(const void* p, bool allow_null) {

@@ -5,7 +5,11 @@ tabulates, per kernel instantiation: VGPRs, AGPRs, SGPRs, scratch bytes per lane
 (waves per SIMD) the register budget allows.  DESIGN.md section 3's claim -- "<= 64 VGPRs, no scratch, 8 waves/SIMD for every
 kernel" -- is read off this table, and tests/test_abi.py holds the library to it.
 
-    python scripts/kernel_resources.py [--out profiles/r4_kernel_resources.txt]
+`--isa` adds an instruction census of the generated gfx950 assembly per kernel: global loads / stores by width, how many of
+them carry the non-temporal bit, LDS and cross-lane instructions, MFMA and scratch instructions (both expected to be zero:
+nothing on this path is GEMM-shaped).
+
+    python scripts/kernel_resources.py [--out profiles/r4_kernel_resources.txt] [--isa --isa-out profiles/r4_kernel_isa_census.txt]
 """
 import argparse
 import os
@@ -78,6 +82,62 @@ def collect():
     return rows
 
 
+ISA_COUNTS = [("ld128", r"global_load_dwordx4"), ("ld64", r"global_load_dwordx2"), ("ld32", r"global_load_(dword|ubyte|sbyte|ushort|sshort)\b"),
+              ("st128", r"global_store_dwordx4"), ("st64", r"global_store_dwordx2"), ("st32", r"global_store_(dword|byte|short)\b"),
+              ("atomics", r"global_atomic|flat_atomic"), ("lds", r"\bds_(read|write|load|store)"), ("xlane", r"ds_bpermute|ds_swizzle|v_readlane|v_permlane|_dpp|row_shr|row_bcast"),
+              ("mfma", r"v_mfma|v_smfmac"), ("scratch", r"scratch_(load|store)|buffer_(load|store)[a-z0-9_]* .*offen")]
+
+
+def isa_census():
+    """{demangled short kernel name: counts} from `hipcc -S --cuda-device-only` of every source."""
+    from breaching_amd import build
+
+    flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for src in build.SOURCES:
+            asm = os.path.join(tmp, src + ".s")
+            cmd = [build._hipcc(), *flags, f"-I{build.INCLUDE}", f"-I{build.CSRC}", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument",
+                   os.path.join(build.CSRC, src), "-o", asm]
+            proc = subprocess.run(cmd, capture_output=True, text=True)
+            if proc.returncode != 0:
+                raise RuntimeError(proc.stderr[-2000:])
+            current, bodies = None, {}
+            with open(asm) as f:
+                for line in f:
+                    m = re.match(r"^(_Z\w+):", line)
+                    if m:
+                        current = m.group(1)
+                        bodies[current] = []
+                        continue
+                    if line.startswith(".Lfunc_end"):
+                        current = None
+                    elif current is not None:
+                        code = line.split(";")[0].strip()
+                        if code and not code.startswith("."):
+                            bodies[current].append(code)
+            names = demangle(list(bodies))
+            for mangled, body in bodies.items():
+                row = dict(source=src, instructions=len(body))
+                for key, pattern in ISA_COUNTS:
+                    row[key] = sum(1 for c in body if re.search(pattern, c))
+                row["ld_nt"] = sum(1 for c in body if re.match(r"global_load", c) and re.search(r"\bnt\b", c))
+                row["st_nt"] = sum(1 for c in body if re.match(r"global_store", c) and re.search(r"\bnt\b", c))
+                out[short(names[mangled])] = row
+    return out
+
+
+def render_isa(census):
+    keys = ["instructions", "ld128", "ld64", "ld32", "ld_nt", "st128", "st64", "st32", "st_nt", "atomics", "lds", "xlane", "mfma", "scratch"]
+    lines = ["# instruction census of the gfx950 assembly (hipcc -O3 -S --cuda-device-only), one line per kernel instantiation",
+             "# ld/st = global loads / stores by width in bits; *_nt = of those, with the non-temporal bit; xlane = DPP / permute / readlane",
+             f"{'kernel':58s} " + " ".join(f"{k:>8s}" for k in keys)]
+    for name, row in census.items():
+        lines.append(f"{name[:58]:58s} " + " ".join(f"{row[k]:8d}" for k in keys))
+    lines.append(f"# {len(census)} kernels; MFMA instructions {sum(r['mfma'] for r in census.values())}, scratch accesses {sum(r['scratch'] for r in census.values())}")
+    return "\n".join(lines) + "\n"
+
+
 def render(rows):
     head = f"{'source':24s} {'kernel':58s} {'VGPR':>5s} {'AGPR':>5s} {'SGPR':>5s} {'scratch':>8s} {'spills':>7s} {'LDS B':>7s} {'waves/SIMD':>10s}"
     lines = ["# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage, one line per kernel instantiation",
@@ -93,12 +153,20 @@ def render(rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--isa", action="store_true")
+    ap.add_argument("--isa-out", default=None)
     args = ap.parse_args()
     text = render(collect())
     if args.out:
         with open(args.out, "w") as f:
             f.write(text)
     sys.stdout.write(text)
+    if args.isa or args.isa_out:
+        text = render_isa(isa_census())
+        if args.isa_out:
+            with open(args.isa_out, "w") as f:
+                f.write(text)
+        sys.stdout.write(text)
 
 
 if __name__ == "__main__":

@@ -334,3 +334,37 @@ def test_static_kernel_resources_no_scratch_and_full_occupancy_for_the_streaming
     with open(os.path.join(root, "profiles", "r4_kernel_resources.txt")) as f:
         committed = f.read()
     assert committed == kernel_resources.render(rows), "profiles/r4_kernel_resources.txt is stale: python scripts/kernel_resources.py --out ..."
+
+
+def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
+    """The generated gfx950 assembly, per kernel (scripts/kernel_resources.py --isa, no GPU): every kernel that streams a list or
+    an activation through HBM does it with 16-byte global loads (the round-2/3 multi-tensor kernel did not: the compiler had
+    scalarised a null-guarded float4 load into four branch-guarded dword loads per operand -- found by this census); kernel A's
+    cache-policy template arguments put the non-temporal bit on exactly the accesses they name (BH_GM_CACHE_*); nothing on the path
+    is GEMM-shaped, so there is no MFMA instruction, and no scratch access."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    census = kernel_resources.isa_census()
+    assert len(census) >= 60
+    assert all(row["mfma"] == 0 and row["scratch"] == 0 for row in census.values())
+    for name, row in census.items():
+        if re.match(r"(gm_fwd|gm_bwd|gm_pack|mt_kernel|bn_sums|bn_bwd|bn_eval_(fwd|bwd))", name):
+            assert row["ld128"] >= 1 and row["st128"] + row["st64"] + row["st32"] >= 1, (name, row)
+        if name.startswith("mt_kernel"):
+            assert row["ld128"] >= 4 * row["ld32"] - 4 and row["st128"] >= 4, (name, row)  # 4-byte accesses only in the ragged tail
+        m = re.match(r"gm_fwd_kernel<(\d+), (true|false)>", name)
+        if m:
+            assert row["ld_nt"] == (row["ld128"] if m.group(2) == "true" else 0), (name, row)
+        m = re.match(r"gm_bwd_kernel<(\d+), (true|false), (true|false)>", name)
+        if m:
+            assert row["ld_nt"] == (row["ld128"] if m.group(2) == "true" else 0), (name, row)
+            assert (row["st_nt"] > 0) == (m.group(3) == "true"), (name, row)
+    with open(os.path.join(root, "profiles", "r4_kernel_isa_census.txt")) as f:
+        committed = f.read()
+    assert committed == kernel_resources.render_isa(census), "profiles/r4_kernel_isa_census.txt is stale: python scripts/kernel_resources.py --isa-out ..."
