@@ -58,7 +58,21 @@ __device__ __forceinline__ float4 mt_elem4(const float4& a, const float4& b, con
 constexpr int kMtIters = BH_GM_CHUNK / 4 / kBlock;
 static_assert(kMtIters * 4 * kBlock == BH_GM_CHUNK, "a chunk is a whole number of 16-byte accesses per thread");
 
-template <int OP, bool HAS_A>
+// NT: the operands are read with non-temporal loads (`global_load_dwordx4 ... nt`), as kernel A does for lists that cannot stay
+// in the 256 MiB Infinity Cache (gm_kernels.hip, BH_GM_CACHE_*): every operand is read once per launch, and the lines of the
+// previous launch's output are still draining.  The output keeps plain stores -- the model's next forward pass reads it.
+typedef float bh_mt_v4f __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 mt_load(const float4* p) {
+  if constexpr (NT) {
+    const bh_mt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const bh_mt_v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *p;
+  }
+}
+
+template <int OP, bool HAS_A, bool NT>
 __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
                                          float* __restrict__ o, int len, float k0, float k1) {
   constexpr bool needs_b = OP != kScale, needs_c = OP == kAxpyMinus || OP == kPatch;
@@ -75,9 +89,9 @@ __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const floa
     const int i = tid + j * kBlock;
     av[j] = bv[j] = cv[j] = zero;
     if (i < n4) {
-      if constexpr (HAS_A) av[j] = a4[i];
-      if constexpr (needs_b) bv[j] = b4[i];
-      if constexpr (needs_c) cv[j] = c4[i];
+      if constexpr (HAS_A) av[j] = mt_load<NT>(a4 + i);
+      if constexpr (needs_b) bv[j] = mt_load<NT>(b4 + i);
+      if constexpr (needs_c) cv[j] = mt_load<NT>(c4 + i);
     }
   }
 #pragma unroll
@@ -98,7 +112,7 @@ __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const floa
 // One workgroup per chunk.  `c_flat`: the third operand comes from a packed buffer (patch) instead of a pointer list.
 // `coef`: device pair overriding (k0, k1) when non-NULL (patch).  A NULL `a` pointer reads as zeros (scale of a missing
 // upstream gradient).
-template <int OP>
+template <int OP, bool NT>
 __global__ __launch_bounds__(kBlock) void mt_kernel(MtPtrs ptrs, int tensor_base, const float* __restrict__ c_flat,
                                                     const bh_gm_chunk* __restrict__ chunks, int chunk_base, float k0,
                                                     float k1, const float* __restrict__ coef, float* __restrict__ out_flat) {
@@ -116,9 +130,9 @@ __global__ __launch_bounds__(kBlock) void mt_kernel(MtPtrs ptrs, int tensor_base
   const float* __restrict__ bp = needs_b ? b + ch.tensor_off : nullptr;
   const float* __restrict__ cp = needs_c ? (c_flat ? c : c + ch.tensor_off) : nullptr;
   if (a)  // uniform over the workgroup
-    mt_chunk<OP, true>(a + ch.tensor_off, bp, cp, o, ch.len, k0, k1);
+    mt_chunk<OP, true, NT>(a + ch.tensor_off, bp, cp, o, ch.len, k0, k1);
   else
-    mt_chunk<OP, false>(nullptr, bp, cp, o, ch.len, k0, k1);
+    mt_chunk<OP, false, NT>(nullptr, bp, cp, o, ch.len, k0, k1);
 }
 
 bool ok_ptr(const void* p, bool allow_null) {
@@ -160,13 +174,24 @@ int run_mt(int32_t n_tensors, const void* const* a, const void* const* b, const 
     if (!fill(probe, a, b, c, n_tensors, g, a_nullable)) return BH_EINVAL;
   }
   hipStream_t st = bh::as_stream(stream);
+  // Footprint of one call = operands read + the list written.  While it fits the 256 MiB Infinity Cache (BH_GM_CACHE_AUTO_BYTES)
+  // plain loads win -- the next call, or the model's forward pass, finds its operands there (ResNet-18, (a + alpha b) - c:
+  // 30.9 us plain vs 33.6 us non-temporal); beyond it the operands are read once and only displace the output: non-temporal
+  // loads (ResNet-50: 71.6 -> 68.4 us and 98.8 -> 89.3 us; BERT-base 197.1 -> 190.8 and 262.0 -> 254.2 us;
+  // profiles/r4_mt_kernel_probe_nt.jsonl).
+  constexpr int kOperands = OP == kScale ? 1 : (OP == kAxpy ? 2 : 3);
+  const bool stream_loads = n_chunks * (int64_t)BH_GM_CHUNK * 4 * (kOperands + 1) > (int64_t)BH_GM_CACHE_AUTO_BYTES;
   for (int g = 0; g < groups; ++g) {
     const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
     if (n <= 0) continue;
     MtPtrs ptrs;
     fill(ptrs, a, b, c, n_tensors, g, a_nullable);
-    hipLaunchKernelGGL(mt_kernel<OP>, dim3(n), dim3(kBlock), 0, st, ptrs, g * BH_MT_MAX_PTRS, c_flat, chunks_dev, begin, k0,
-                       k1, coef, out_flat);
+    if (stream_loads)
+      hipLaunchKernelGGL((mt_kernel<OP, true>), dim3(n), dim3(kBlock), 0, st, ptrs, g * BH_MT_MAX_PTRS, c_flat, chunks_dev, begin,
+                         k0, k1, coef, out_flat);
+    else
+      hipLaunchKernelGGL((mt_kernel<OP, false>), dim3(n), dim3(kBlock), 0, st, ptrs, g * BH_MT_MAX_PTRS, c_flat, chunks_dev, begin,
+                         k0, k1, coef, out_flat);
     const int rc = bh::launch_status();
     if (rc != 0) return rc;
   }

@@ -358,6 +358,9 @@ def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
             assert row["ld128"] >= 1 and row["st128"] + row["st64"] + row["st32"] >= 1, (name, row)
         if name.startswith("mt_kernel"):
             assert row["ld128"] >= 4 * row["ld32"] - 4 and row["st128"] >= 4, (name, row)  # 4-byte accesses only in the ragged tail
+        m = re.match(r"(gm_fwd_kernel|mt_kernel)<(\d+), (true|false)>", name)
+        if m:  # kernel A forward and the multi-tensor kernels: the template flag puts `nt` on every 16-byte load, or on none
+            assert row["ld_nt"] == (row["ld128"] if m.group(3) == "true" else 0) and row["st_nt"] == 0, (name, row)
         m = re.match(r"gm_fwd_kernel<(\d+), (true|false)>", name)
         if m:
             assert row["ld_nt"] == (row["ld128"] if m.group(2) == "true" else 0), (name, row)
