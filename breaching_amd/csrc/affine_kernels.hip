@@ -71,6 +71,19 @@ __device__ __forceinline__ void slab_range(int B, int HW, int S, int slab, bool 
   v1 = (uint32_t)((uint64_t)total * ((uint32_t)slab + 1u) / (uint32_t)S);
 }
 
+// element (float4 or float) `u` of the channel's virtual array -> offset in the [B, C, HW] tensor, in the same units
+__device__ __forceinline__ size_t slab_offset(uint32_t u, int B, uint32_t unit, size_t cstride, size_t cbase) {
+  const uint32_t b = B == 1 ? 0u : u / unit;
+  return (size_t)b * cstride + cbase + (u - b * unit);
+}
+
+// 16-byte loads per operand that a lane issues before it uses the first one.  At B = 1 these kernels run 32-128 workgroups, at
+// most one wavefront per SIMD, so nothing hides a load's latency but the lane's own next loads: with the plain
+// load-use-store loop of rounds 3-4 a ResNet-18 layer-1 launch (784 float4 per channel over 256 lanes) was three to four serial
+// memory round trips (instruction census, profiles/r4_kernel_isa_census.txt); staged, it is one.  The order in which a lane
+// accumulates its channel sums is unchanged, so every result is bit-identical to the unstaged kernels.
+constexpr int kStage = 4;
+
 // per-channel(-slab) sums of K doubles: wide = block_sum, narrow = wave_sum; result valid in lane 0 of the owner
 template <int K>
 __device__ __forceinline__ void channel_sum(double (&v)[K], bool narrow, double* lds) {
@@ -105,36 +118,59 @@ __global__ __launch_bounds__(kBlock) void bn_eval_fwd_kernel(const float* __rest
     const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
     float a0 = 0.f, a1 = 0.f;
     int cnt = 0;
-    for (uint32_t v = v0 + (uint32_t)w.lane; v < v1; v += (uint32_t)w.lanes) {
-      const uint32_t b = B == 1 ? 0u : v / unit, j = v - b * unit;
-      const size_t at = (size_t)b * cstride + cbase + j;
-      if (vec) {
-        const float4 q = reinterpret_cast<const float4*>(x)[at];
-        if (resid == nullptr && !relu) {
-          reinterpret_cast<float4*>(y)[at] = make_float4(fmaf(q.x, s, t), fmaf(q.y, s, t), fmaf(q.z, s, t), fmaf(q.w, s, t));
-        } else {
-          const float4 r = resid ? reinterpret_cast<const float4*>(resid)[at] : make_float4(0.f, 0.f, 0.f, 0.f);
-          reinterpret_cast<float4*>(y)[at] = make_float4(act(fmaf(q.x, s, t), r.x), act(fmaf(q.y, s, t), r.y), act(fmaf(q.z, s, t), r.z),
-                                                         act(fmaf(q.w, s, t), r.w));
+    auto flush = [&]() {  // at most 32 values per fp32 accumulator, like bn_sums_kernel
+      if (cnt >= 32) {
+        sums[0] += (double)a0;
+        sums[1] += (double)a1;
+        a0 = a1 = 0.f;
+        cnt = 0;
+      }
+    };
+    if (vec) {
+      const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+      const float4* __restrict__ r4 = reinterpret_cast<const float4*>(resid);
+      float4* __restrict__ y4 = reinterpret_cast<float4*>(y);
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t step = (uint32_t)w.lanes;
+      for (uint32_t v = v0 + (uint32_t)w.lane; v < v1; v += step * kStage) {
+        float4 q[kStage], r[kStage];
+        size_t at[kStage];
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {  // every load of this round is issued before the first use (see kStage)
+          const uint32_t u = v + (uint32_t)k * step;
+          at[k] = slab_offset(u < v1 ? u : v, B, unit, cstride, cbase);  // past the end: re-read the lane's first element, unused
+          q[k] = x4[at[k]];
+          r[k] = zero;
+          if (resid) r[k] = r4[at[k]];
         }
-        a0 += (q.x + q.y) + (q.z + q.w);
-        a1 = fmaf(q.x, q.x, a1);
-        a1 = fmaf(q.y, q.y, a1);
-        a1 = fmaf(q.z, q.z, a1);
-        a1 = fmaf(q.w, q.w, a1);
-        cnt += 4;
-      } else {
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+          const uint32_t u = v + (uint32_t)k * step;
+          if (u < v1) {
+            if (resid == nullptr && !relu)
+              y4[at[k]] = make_float4(fmaf(q[k].x, s, t), fmaf(q[k].y, s, t), fmaf(q[k].z, s, t), fmaf(q[k].w, s, t));
+            else
+              y4[at[k]] = make_float4(act(fmaf(q[k].x, s, t), r[k].x), act(fmaf(q[k].y, s, t), r[k].y), act(fmaf(q[k].z, s, t), r[k].z),
+                                      act(fmaf(q[k].w, s, t), r[k].w));
+            a0 += (q[k].x + q[k].y) + (q[k].z + q[k].w);
+            a1 = fmaf(q[k].x, q[k].x, a1);
+            a1 = fmaf(q[k].y, q[k].y, a1);
+            a1 = fmaf(q[k].z, q[k].z, a1);
+            a1 = fmaf(q[k].w, q[k].w, a1);
+            cnt += 4;
+            flush();
+          }
+        }
+      }
+    } else {
+      for (uint32_t v = v0 + (uint32_t)w.lane; v < v1; v += (uint32_t)w.lanes) {
+        const size_t at = slab_offset(v, B, unit, cstride, cbase);
         const float q = x[at];
         y[at] = (resid == nullptr && !relu) ? fmaf(q, s, t) : act(fmaf(q, s, t), resid ? resid[at] : 0.f);
         a0 += q;
         a1 = fmaf(q, q, a1);
         cnt += 1;
-      }
-      if (cnt >= 32) {  // at most 32 values per fp32 accumulator, like bn_sums_kernel
-        sums[0] += (double)a0;
-        sums[1] += (double)a1;
-        a0 = a1 = 0.f;
-        cnt = 0;
+        flush();
       }
     }
     sums[0] += (double)a0;
@@ -178,33 +214,71 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
     const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
     float a0 = 0.f, a1 = 0.f;
     int cnt = 0;
-    for (uint32_t u = v0 + (uint32_t)w.lane; u < v1; u += (uint32_t)w.lanes) {
-      const uint32_t b = B == 1 ? 0u : u / unit, j = u - b * unit;
-      const size_t at = (size_t)b * cstride + cbase + j;
-      if (vec) {
-        float4 g = reinterpret_cast<const float4*>(gy)[at];
-        const float4 q = reinterpret_cast<const float4*>(x)[at];
-        if (ymask) {
-          const float4 m = reinterpret_cast<const float4*>(ymask)[at];
-          g = make_float4(m.x > 0.f ? g.x : 0.f, m.y > 0.f ? g.y : 0.f, m.z > 0.f ? g.z : 0.f, m.w > 0.f ? g.w : 0.f);
+    auto flush = [&]() {  // at most 32 values per fp32 accumulator
+      if (cnt >= 32) {
+        v[0] += (double)a0;
+        v[1] += (double)a1;
+        a0 = a1 = 0.f;
+        cnt = 0;
+      }
+    };
+    if (vec) {
+      const float4* __restrict__ gy4 = reinterpret_cast<const float4*>(gy);
+      const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+      // without a mask the mask operand reads gy again (the line is in flight already: no HBM traffic) -- an `if (ymask)` around
+      // the load lets the compiler sink the masking into it, and with it a wait for the load, in the middle of the load phase
+      const float4* m4 = reinterpret_cast<const float4*>(ymask ? ymask : gy);
+      const float4* __restrict__ e4 = reinterpret_cast<const float4*>(add_in);
+      float4* __restrict__ gres4 = reinterpret_cast<float4*>(gres);
+      float4* __restrict__ gx4 = reinterpret_cast<float4*>(gx);
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t step = (uint32_t)w.lanes;
+      for (uint32_t u0 = v0 + (uint32_t)w.lane; u0 < v1; u0 += step * kStage) {
+        float4 gv[kStage], qv[kStage], mv[kStage], ev[kStage];
+        size_t at[kStage];
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {  // every load of this round before the first use
+          const uint32_t u = u0 + (uint32_t)k * step;
+          at[k] = slab_offset(u < v1 ? u : u0, B, unit, cstride, cbase);  // past the end: re-read the lane's first element, unused
+          gv[k] = gy4[at[k]];
+          qv[k] = x4[at[k]];
+          mv[k] = m4[at[k]];
+          ev[k] = zero;
+          if (gx && add_in) ev[k] = e4[at[k]];
         }
-        if (gres) reinterpret_cast<float4*>(gres)[at] = g;
-        if (gx) {
-          float4 o = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
-          if (tap_coef) o = make_float4(o.x + fmaf(tb, q.x, ta), o.y + fmaf(tb, q.y, ta), o.z + fmaf(tb, q.z, ta), o.w + fmaf(tb, q.w, ta));
-          if (add_in) {  // the other gradient of this BatchNorm input (from the derivative of this very backward): autograd's add, in here
-            const float4 e = reinterpret_cast<const float4*>(add_in)[at];
-            o = make_float4(o.x + e.x, o.y + e.y, o.z + e.z, o.w + e.w);
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+          const uint32_t u = u0 + (uint32_t)k * step;
+          if (u < v1) {
+            float4 g = gv[k];
+            const float4 q = qv[k];
+            if (ymask) {
+              const float4 m = mv[k];
+              g = make_float4(m.x > 0.f ? g.x : 0.f, m.y > 0.f ? g.y : 0.f, m.z > 0.f ? g.z : 0.f, m.w > 0.f ? g.w : 0.f);
+            }
+            if (gres) gres4[at[k]] = g;
+            if (gx) {
+              float4 o = make_float4(g.x * s, g.y * s, g.z * s, g.w * s);
+              if (tap_coef) o = make_float4(o.x + fmaf(tb, q.x, ta), o.y + fmaf(tb, q.y, ta), o.z + fmaf(tb, q.z, ta), o.w + fmaf(tb, q.w, ta));
+              if (add_in) {  // the other gradient of this BatchNorm input (from the derivative of this very backward): autograd's add, in here
+                const float4 e = ev[k];
+                o = make_float4(o.x + e.x, o.y + e.y, o.z + e.z, o.w + e.w);
+              }
+              gx4[at[k]] = o;
+            }
+            a0 += (g.x + g.y) + (g.z + g.w);
+            a1 = fmaf(g.x, q.x, a1);
+            a1 = fmaf(g.y, q.y, a1);
+            a1 = fmaf(g.z, q.z, a1);
+            a1 = fmaf(g.w, q.w, a1);
+            cnt += 4;
+            flush();
           }
-          reinterpret_cast<float4*>(gx)[at] = o;
         }
-        a0 += (g.x + g.y) + (g.z + g.w);
-        a1 = fmaf(g.x, q.x, a1);
-        a1 = fmaf(g.y, q.y, a1);
-        a1 = fmaf(g.z, q.z, a1);
-        a1 = fmaf(g.w, q.w, a1);
-        cnt += 4;
-      } else {
+      }
+    } else {
+      for (uint32_t u = v0 + (uint32_t)w.lane; u < v1; u += (uint32_t)w.lanes) {
+        const size_t at = slab_offset(u, B, unit, cstride, cbase);
         float g = gy[at];
         const float q = x[at];
         if (ymask && !(ymask[at] > 0.f)) g = 0.f;
@@ -213,12 +287,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
         a0 += g;
         a1 = fmaf(g, q, a1);
         cnt += 1;
-      }
-      if (cnt >= 32) {  // at most 32 values per fp32 accumulator
-        v[0] += (double)a0;
-        v[1] += (double)a1;
-        a0 = a1 = 0.f;
-        cnt = 0;
+        flush();
       }
     }
     v[0] += (double)a0;
@@ -260,36 +329,68 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
     const size_t cstride = (size_t)C * unit, cbase = (size_t)w.c * unit;
     float a0 = 0.f;
     int cnt = 0;
-    for (uint32_t u = v0 + (uint32_t)w.lane; u < v1; u += (uint32_t)w.lanes) {
-      const uint32_t b = B == 1 ? 0u : u / unit, j = u - b * unit;
-      const size_t at = (size_t)b * cstride + cbase + j;
-      if (vec) {
-        float4 g = reinterpret_cast<const float4*>(gy)[at];
-        const float4 q = ggx ? reinterpret_cast<const float4*>(ggx)[at] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (ymask) {
-          const float4 yv = reinterpret_cast<const float4*>(ymask)[at];
-          m = make_float4(yv.x > 0.f ? 1.f : 0.f, yv.y > 0.f ? 1.f : 0.f, yv.z > 0.f ? 1.f : 0.f, yv.w > 0.f ? 1.f : 0.f);
-          g = make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);  // gz
+    auto flush = [&]() {
+      if (cnt >= 32) {
+        v[0] += (double)a0;
+        a0 = 0.f;
+        cnt = 0;
+      }
+    };
+    if (vec) {
+      const float4* __restrict__ gy4 = reinterpret_cast<const float4*>(gy);
+      const float4* __restrict__ ggx4 = reinterpret_cast<const float4*>(ggx);
+      const float4* m4 = reinterpret_cast<const float4*>(ymask ? ymask : gy);  // see bn_eval_bwd_kernel
+      const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+      const float4* __restrict__ r4 = reinterpret_cast<const float4*>(ggr);
+      float4* __restrict__ d_gy4 = reinterpret_cast<float4*>(d_gy);
+      float4* __restrict__ d_x4 = reinterpret_cast<float4*>(d_x);
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t step = (uint32_t)w.lanes;
+      for (uint32_t u0 = v0 + (uint32_t)w.lane; u0 < v1; u0 += step * kStage) {
+        float4 gv[kStage], qv[kStage], yv[kStage], xv[kStage], rv[kStage];
+        size_t at[kStage];
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {  // every load of this round before the first use
+          const uint32_t u = u0 + (uint32_t)k * step;
+          at[k] = slab_offset(u < v1 ? u : u0, B, unit, cstride, cbase);  // past the end: re-read the lane's first element, unused
+          gv[k] = gy4[at[k]];
+          qv[k] = xv[k] = rv[k] = zero;
+          yv[k] = m4[at[k]];
+          if (ggx) qv[k] = ggx4[at[k]];
+          if (d_gy) xv[k] = x4[at[k]];
+          if (d_gy && ggr) rv[k] = r4[at[k]];
         }
-        if (d_gy) {
-          const float4 xv = reinterpret_cast<const float4*>(x)[at];
-          float4 o = make_float4(fmaf(q.x, s, fmaf(kwi, xv.x, shift)), fmaf(q.y, s, fmaf(kwi, xv.y, shift)),
-                                 fmaf(q.z, s, fmaf(kwi, xv.z, shift)), fmaf(q.w, s, fmaf(kwi, xv.w, shift)));
-          if (ggr) {
-            const float4 rr = reinterpret_cast<const float4*>(ggr)[at];
-            o = make_float4(o.x + rr.x, o.y + rr.y, o.z + rr.z, o.w + rr.w);
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+          const uint32_t u = u0 + (uint32_t)k * step;
+          if (u < v1) {
+            float4 g = gv[k];
+            const float4 q = qv[k];
+            float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (ymask) {
+              m = make_float4(yv[k].x > 0.f ? 1.f : 0.f, yv[k].y > 0.f ? 1.f : 0.f, yv[k].z > 0.f ? 1.f : 0.f, yv[k].w > 0.f ? 1.f : 0.f);
+              g = make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);  // gz
+            }
+            if (d_gy) {
+              float4 o = make_float4(fmaf(q.x, s, fmaf(kwi, xv[k].x, shift)), fmaf(q.y, s, fmaf(kwi, xv[k].y, shift)),
+                                     fmaf(q.z, s, fmaf(kwi, xv[k].z, shift)), fmaf(q.w, s, fmaf(kwi, xv[k].w, shift)));
+              if (ggr) o = make_float4(o.x + rv[k].x, o.y + rv[k].y, o.z + rv[k].z, o.w + rv[k].w);
+              if (ymask) o = make_float4(m.x > 0.f ? o.x : 0.f, m.y > 0.f ? o.y : 0.f, m.z > 0.f ? o.z : 0.f, m.w > 0.f ? o.w : 0.f);
+              d_gy4[at[k]] = o;
+            }
+            if (d_x) d_x4[at[k]] = make_float4(kwi * g.x, kwi * g.y, kwi * g.z, kwi * g.w);
+            a0 = fmaf(q.x, g.x, a0);
+            a0 = fmaf(q.y, g.y, a0);
+            a0 = fmaf(q.z, g.z, a0);
+            a0 = fmaf(q.w, g.w, a0);
+            cnt += 4;
+            flush();
           }
-          if (ymask) o = make_float4(m.x > 0.f ? o.x : 0.f, m.y > 0.f ? o.y : 0.f, m.z > 0.f ? o.z : 0.f, m.w > 0.f ? o.w : 0.f);
-          reinterpret_cast<float4*>(d_gy)[at] = o;
         }
-        if (d_x) reinterpret_cast<float4*>(d_x)[at] = make_float4(kwi * g.x, kwi * g.y, kwi * g.z, kwi * g.w);
-        a0 = fmaf(q.x, g.x, a0);
-        a0 = fmaf(q.y, g.y, a0);
-        a0 = fmaf(q.z, g.z, a0);
-        a0 = fmaf(q.w, g.w, a0);
-        cnt += 4;
-      } else {
+      }
+    } else {
+      for (uint32_t u = v0 + (uint32_t)w.lane; u < v1; u += (uint32_t)w.lanes) {
+        const size_t at = slab_offset(u, B, unit, cstride, cbase);
         float g = gy[at];
         const float q = ggx ? ggx[at] : 0.f;
         const bool on = ymask == nullptr || ymask[at] > 0.f;
@@ -298,11 +399,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
         if (d_x) d_x[at] = kwi * g;
         a0 = fmaf(q, g, a0);
         cnt += 1;
-      }
-      if (cnt >= 32) {
-        v[0] += (double)a0;
-        a0 = 0.f;
-        cnt = 0;
+        flush();
       }
     }
     v[0] += (double)a0;

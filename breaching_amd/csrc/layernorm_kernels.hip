@@ -28,6 +28,37 @@ __device__ __forceinline__ double wave_allsum(double v) {
   return v;
 }
 
+// Loads per operand that a lane issues before it uses the first one.  A 32 x 768 activation is 32 wavefronts in 8 workgroups:
+// nothing hides a load's latency but the lane's own next loads, and the plain load-use loops of round 3 made a row kernel
+// 2 x 12 serial memory round trips (instruction census, profiles/r4_kernel_isa_census.txt); staged, 2 x 3.  Each lane still visits
+// its elements in ascending order, so every sum is accumulated in the same order and the results are bit-identical.
+constexpr int kLnStage = 4;
+
+// i = first, first + stride, ... < end: `load(i)` for kLnStage positions, then `use(i, value)` for the same positions in order
+template <typename V, typename Load, typename Use>
+__device__ __forceinline__ void staged_walk(int first, int end, int stride, Load load, Use use) {
+  for (int i0 = first; i0 < end; i0 += stride * kLnStage) {
+    V v[kLnStage];
+#pragma unroll
+    for (int k = 0; k < kLnStage; ++k) {
+      const int i = i0 + k * stride;
+      v[k] = load(i < end ? i : i0);  // past the end: re-read the lane's first position, unused
+    }
+#pragma unroll
+    for (int k = 0; k < kLnStage; ++k) {
+      const int i = i0 + k * stride;
+      if (i < end) use(i, v[k]);
+    }
+  }
+}
+
+struct Ln3 {
+  float a, b, c;
+};
+struct Ln6 {
+  float gy, gm, x, u, s, t;
+};
+
 __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float* __restrict__ y,
                                                         float* __restrict__ mean, float* __restrict__ rstd, int R, int D,
@@ -36,11 +67,12 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const float* __restrict_
   if (r >= R) return;
   const float* __restrict__ xr = x + (size_t)r * D;
   double s0 = 0.0, s1 = 0.0;
-  for (int i = lane; i < D; i += bh::kWave) {
-    const double v = (double)xr[i];
-    s0 += v;
-    s1 += v * v;
-  }
+  staged_walk<float>(lane, D, bh::kWave, [&](int i) { return xr[i]; },
+                     [&](int, float xv) {
+                       const double v = (double)xv;
+                       s0 += v;
+                       s1 += v * v;
+                     });
   s0 = wave_allsum(s0);
   s1 = wave_allsum(s1);
   const double mu = s0 / D;
@@ -52,10 +84,22 @@ __global__ __launch_bounds__(kBlock) void ln_fwd_kernel(const float* __restrict_
     rstd[r] = rs;
   }
   float* __restrict__ yr = y + (size_t)r * D;
-  for (int i = lane; i < D; i += bh::kWave) {
-    const float xh = (xr[i] - m) * rs;
-    yr[i] = fmaf(xh, gamma ? gamma[i] : 1.f, beta ? beta[i] : 0.f);
-  }
+  // A missing operand reads the row instead and is ignored after the load (`absent`, below): a branch around an optional load
+  // lets the compiler sink the first use into it, and with it a wait for the load, in the middle of the load phase.
+  const float* gp = gamma ? gamma : xr;
+  const float* bp = beta ? beta : xr;
+  staged_walk<Ln3>(lane, D, bh::kWave,
+                   [&](int i) {
+                     Ln3 v;
+                     v.a = xr[i];
+                     v.b = gp[i];
+                     v.c = bp[i];
+                     return v;
+                   },
+                   [&](int i, const Ln3& v) {
+                     const float xh = (v.a - m) * rs;
+                     yr[i] = fmaf(xh, gamma ? v.b : 1.f, beta ? v.c : 0.f);
+                   });
 }
 
 __global__ __launch_bounds__(kBlock) void ln_bwd_row_kernel(const float* __restrict__ gy, const float* __restrict__ x,
@@ -66,28 +110,37 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_row_kernel(const float* __restr
   const size_t base = (size_t)r * D;
   const float m = mean[r], rs = rstd[r];
   double s0 = 0.0, s1 = 0.0;  // sum g, sum g x_hat
-  for (int i = lane; i < D; i += bh::kWave) {
-    const float g = gy[base + i] * (gamma ? gamma[i] : 1.f);
-    const float xh = (x[base + i] - m) * rs;
+  const float* gp = gamma ? gamma : x + base;  // a missing operand reads the row instead and is ignored (see ln_fwd_kernel)
+  auto load = [&](int i) {
+    Ln3 v;
+    v.a = gy[base + i];
+    v.b = gp[i];
+    v.c = x[base + i];
+    return v;
+  };
+  staged_walk<Ln3>(lane, D, bh::kWave, load, [&](int, const Ln3& v) {
+    const float g = v.a * (gamma ? v.b : 1.f);
+    const float xh = (v.c - m) * rs;
     s0 += (double)g;
     s1 += (double)g * (double)xh;
-  }
+  });
   const float a = (float)(wave_allsum(s0) / D), b = (float)(wave_allsum(s1) / D);
-  for (int i = lane; i < D; i += bh::kWave) {
-    const float g = gy[base + i] * (gamma ? gamma[i] : 1.f);
-    const float xh = (x[base + i] - m) * rs;
+  staged_walk<Ln3>(lane, D, bh::kWave, load, [&](int i, const Ln3& v) {
+    const float g = v.a * (gamma ? v.b : 1.f);
+    const float xh = (v.c - m) * rs;
     gx[base + i] = rs * (g - a - xh * b);
-  }
+  });
 }
 
 // sums over rows for 64 columns per workgroup: thread (col = tid & 63, phase = tid >> 6) walks rows phase, phase + 4, ...
-template <typename Term>
-__device__ __forceinline__ void column_sums(int R, int D, double (&acc)[2], Term term, float* out0, float* out1) {
+// (`load(r, col)` staged kLnStage rows ahead of `use(r, value, acc)`, rows in ascending order)
+template <typename V, typename Load, typename Use>
+__device__ __forceinline__ void column_sums(int R, int D, double (&acc)[2], Load load, Use use, float* out0, float* out1) {
   __shared__ double lds[kBlock * 2];
   const int col = blockIdx.x * bh::kWave + (threadIdx.x & (bh::kWave - 1)), phase = threadIdx.x >> 6;
   acc[0] = acc[1] = 0.0;
   if (col < D)
-    for (int r = phase; r < R; r += bh::kWavesPerBlock) term(r, col, acc);
+    staged_walk<V>(phase, R, bh::kWavesPerBlock, [&](int r) { return load(r, col); }, [&](int r, const V& v) { use(r, v, acc); });
   lds[threadIdx.x * 2] = acc[0];
   lds[threadIdx.x * 2 + 1] = acc[1];
   __syncthreads();
@@ -102,18 +155,31 @@ __device__ __forceinline__ void column_sums(int R, int D, double (&acc)[2], Term
   }
 }
 
+struct LnCol {
+  float gy, x, mean, rstd, u, m0, m1;
+};
+
 __global__ __launch_bounds__(kBlock) void ln_bwd_col_kernel(const float* __restrict__ gy, const float* __restrict__ x,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ ggamma, float* __restrict__ gbeta, int R, int D) {
   double acc[2];
-  column_sums(R, D, acc,
-              [&](int r, int col, double (&a)[2]) {
-                const float g = gy[(size_t)r * D + col];
-                const float xh = (x[(size_t)r * D + col] - mean[r]) * rstd[r];
-                a[0] += (double)g * (double)xh;
-                a[1] += (double)g;
-              },
-              ggamma, gbeta);
+  column_sums<LnCol>(R, D, acc,
+                     [&](int r, int col) {
+                       LnCol v;
+                       v.gy = gy[(size_t)r * D + col];
+                       v.x = x[(size_t)r * D + col];
+                       v.mean = mean[r];
+                       v.rstd = rstd[r];
+                       v.u = v.m0 = v.m1 = 0.f;
+                       return v;
+                     },
+                     [&](int, const LnCol& v, double (&a)[2]) {
+                       const float g = v.gy;
+                       const float xh = (v.x - v.mean) * v.rstd;
+                       a[0] += (double)g * (double)xh;
+                       a[1] += (double)g;
+                     },
+                     ggamma, gbeta);
 }
 
 // row_scalars[r] = (M(u), M(u x_hat)): what the column kernel needs to rebuild P u
@@ -128,12 +194,40 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_bwd_row_kernel(const float* __r
   const size_t base = (size_t)r * D;
   const float m = mean[r], rs = rstd[r];
   double su = 0.0, sux = 0.0, sg = 0.0, sgx = 0.0, sug = 0.0, sq = 0.0, sqx = 0.0;
-  for (int i = lane; i < D; i += bh::kWave) {
-    const float gyv = gy[base + i];
-    const float g = gyv * (gamma ? gamma[i] : 1.f);
-    const float xh = (x[base + i] - m) * rs;
-    const float uv = u ? u[base + i] : 0.f;
-    const float q = s ? s[i] * gyv : 0.f;
+  // a missing operand reads the row of x instead and is replaced by its neutral value after the load (see ln_fwd_kernel)
+  const float* gp = gamma ? gamma : x + base;
+  const float* up = u ? u + base : x + base;
+  const float* sp = s ? s : x + base;
+  const float* tp = t ? t : x + base;
+  auto neutral = [&](Ln6 v) {
+    v.gm = gamma ? v.gm : 1.f;
+    v.u = u ? v.u : 0.f;
+    v.s = s ? v.s : 0.f;
+    v.t = t ? v.t : 0.f;
+    return v;
+  };
+  auto load_sums = [&](int i) {  // first pass: everything but t
+    Ln6 v;
+    v.gy = gy[base + i];
+    v.x = x[base + i];
+    v.gm = gp[i];
+    v.u = up[i];
+    v.s = sp[i];
+    v.t = 0.f;
+    return v;
+  };
+  auto load = [&](int i) {
+    Ln6 v = load_sums(i);
+    v.t = tp[i];
+    return v;
+  };
+  staged_walk<Ln6>(lane, D, bh::kWave, load_sums, [&](int, const Ln6& loaded) {
+    const Ln6 v = neutral(loaded);
+    const float gyv = v.gy;
+    const float g = gyv * v.gm;
+    const float xh = (v.x - m) * rs;
+    const float uv = v.u;
+    const float q = s ? v.s * gyv : 0.f;
     su += (double)uv;
     sux += (double)uv * (double)xh;
     sg += (double)g;
@@ -141,7 +235,7 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_bwd_row_kernel(const float* __r
     sug += (double)uv * (double)g;
     sq += (double)q;
     sqx += (double)q * (double)xh;
-  }
+  });
   const double inv = 1.0 / D;
   const double Mu = wave_allsum(su) * inv, Mux = wave_allsum(sux) * inv, a = wave_allsum(sg) * inv, b = wave_allsum(sgx) * inv;
   const double Mug = wave_allsum(sug) * inv, Mq = wave_allsum(sq) * inv, Mqx = wave_allsum(sqx) * inv;
@@ -152,19 +246,20 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_bwd_row_kernel(const float* __r
     row_scalars[2 * r + 1] = fMux;
   }
   const float rs2 = rs * rs;
-  for (int i = lane; i < D; i += bh::kWave) {
-    const float gyv = gy[base + i];
-    const float gm = gamma ? gamma[i] : 1.f;
+  staged_walk<Ln6>(lane, D, bh::kWave, load, [&](int i, const Ln6& loaded) {
+    const Ln6 v = neutral(loaded);
+    const float gyv = v.gy;
+    const float gm = v.gm;
     const float g = gyv * gm;
-    const float xh = (x[base + i] - m) * rs;
-    const float uv = u ? u[base + i] : 0.f;
-    const float sv = s ? s[i] : 0.f;
+    const float xh = (v.x - m) * rs;
+    const float uv = v.u;
+    const float sv = v.s;
     const float q = sv * gyv;
     const float Pu = uv - fMu - xh * fMux;
     const float w = g - fa - xh * fb;
-    if (d_gy) d_gy[base + i] = gm * rs * Pu + sv * xh + (t ? t[i] : 0.f);
+    if (d_gy) d_gy[base + i] = gm * rs * Pu + sv * xh + v.t;
     if (d_x) d_x[base + i] = -rs2 * (Muw * xh + fb * Pu + fMux * w) + rs * (q - fMq - xh * fMqx);
-  }
+  });
 }
 
 __global__ __launch_bounds__(kBlock) void ln_bwd_bwd_col_kernel(const float* __restrict__ u, const float* __restrict__ gy,
@@ -173,14 +268,25 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_bwd_col_kernel(const float* __r
                                                                 const float* __restrict__ row_scalars, float* __restrict__ d_gamma,
                                                                 int R, int D) {
   double acc[2];
-  column_sums(R, D, acc,
-              [&](int r, int col, double (&a)[2]) {
-                const float rs = rstd[r];
-                const float xh = (x[(size_t)r * D + col] - mean[r]) * rs;
-                const float Pu = u[(size_t)r * D + col] - row_scalars[2 * r] - xh * row_scalars[2 * r + 1];
-                a[0] += (double)gy[(size_t)r * D + col] * (double)(rs * Pu);
-              },
-              d_gamma, static_cast<float*>(nullptr));
+  column_sums<LnCol>(R, D, acc,
+                     [&](int r, int col) {
+                       LnCol v;
+                       v.gy = gy[(size_t)r * D + col];
+                       v.x = x[(size_t)r * D + col];
+                       v.u = u[(size_t)r * D + col];
+                       v.mean = mean[r];
+                       v.rstd = rstd[r];
+                       v.m0 = row_scalars[2 * r];
+                       v.m1 = row_scalars[2 * r + 1];
+                       return v;
+                     },
+                     [&](int, const LnCol& v, double (&a)[2]) {
+                       const float rs = v.rstd;
+                       const float xh = (v.x - v.mean) * rs;
+                       const float Pu = v.u - v.m0 - xh * v.m1;
+                       a[0] += (double)v.gy * (double)(rs * Pu);
+                     },
+                     d_gamma, static_cast<float*>(nullptr));
 }
 
 bool ln_args_ok(const void* x, int32_t R, int32_t D) { return x != nullptr && R > 0 && D > 0 && (int64_t)R * D < ((int64_t)1 << 40); }
