@@ -9,7 +9,13 @@ kernel" -- is read off this table, and tests/test_abi.py holds the library to it
 them carry the non-temporal bit, LDS and cross-lane instructions, MFMA and scratch instructions (both expected to be zero:
 nothing on this path is GEMM-shaped).
 
+`--loops` lists every loop of the generated code that loads from global memory: loads and stores per trip and the
+`s_waitcnt vmcnt(0)` in it -- a trip with one or two loads and a full wait is a serial memory round trip per trip, harmless
+in a kernel that runs thousands of wavefronts, the whole cost of one that runs a wavefront per SIMD (how kernels E and F
+were found in round 4).
+
     python scripts/kernel_resources.py [--out profiles/r4_kernel_resources.txt] [--isa --isa-out profiles/r4_kernel_isa_census.txt]
+                                       [--loops --loops-out profiles/r4_kernel_loop_census.txt]
 """
 import argparse
 import os
@@ -88,12 +94,12 @@ ISA_COUNTS = [("ld128", r"global_load_dwordx4"), ("ld64", r"global_load_dwordx2"
               ("mfma", r"v_mfma|v_smfmac"), ("scratch", r"scratch_(load|store)|buffer_(load|store)[a-z0-9_]* .*offen")]
 
 
-def isa_census():
-    """{demangled short kernel name: counts} from `hipcc -S --cuda-device-only` of every source."""
+def kernel_bodies(keep_labels=False):
+    """[(source, demangled short name, [assembly lines])] from `hipcc -S --cuda-device-only` of every source."""
     from breaching_amd import build
 
     flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
-    out = {}
+    out = []
     with tempfile.TemporaryDirectory() as tmp:
         for src in build.SOURCES:
             asm = os.path.join(tmp, src + ".s")
@@ -113,17 +119,70 @@ def isa_census():
                     if line.startswith(".Lfunc_end"):
                         current = None
                     elif current is not None:
+                        if keep_labels:
+                            if line.strip():
+                                bodies[current].append(line.rstrip())
+                            continue
                         code = line.split(";")[0].strip()
                         if code and not code.startswith("."):
                             bodies[current].append(code)
             names = demangle(list(bodies))
-            for mangled, body in bodies.items():
+            out.extend((src, short(names[mangled]), body) for mangled, body in bodies.items())
+    return out
+
+
+def loop_census():
+    """One row per loop that loads from global memory: kernel, loop header, depth, loads / stores / full waits / partial waits per trip.
+    Loop membership comes from the compiler's own block annotations (`Loop Header` / `in Loop: Header=BBn_m`): the blocks of a
+    rotated loop lie on both sides of its header."""
+    rows = []
+    for src, name, lines in kernel_bodies(keep_labels=True):
+        blocks, current = [], None  # [label, annotation, [code]]
+        for line in lines:
+            m = re.match(r"^(\.LBB\d+_\d+):\s*(;.*)?$", line) or re.match(r"^; %bb\.(\d+):\s*(;.*)?$", line)
+            if m:
+                current = [m.group(1), m.group(2) or "", []]
+                blocks.append(current)
+            elif current is not None:
+                code = line.split(";")[0].strip()
+                if code and not code.startswith("."):
+                    current[2].append(code)
+        for label, note, _ in blocks:
+            m = re.search(r"Loop Header: Depth=(\d+)", note)
+            if not m:
+                continue
+            key = label.replace(".L", "")
+            trip = [c for lab, n, code in blocks if lab == label or re.search(r"in Loop: Header=" + re.escape(key) + r"\b", n) for c in code]
+            loads = sum("global_load" in x for x in trip)
+            if not loads:
+                continue
+            rows.append(dict(source=src, kernel=name, loop=label, depth=int(m.group(1)), loads=loads, stores=sum("global_store" in x for x in trip),
+                             full_waits=sum(bool(re.search(r"s_waitcnt.*vmcnt\(0\)", x)) for x in trip),
+                             partial_waits=sum(bool(re.search(r"s_waitcnt.*vmcnt\([1-9]", x)) for x in trip), instructions=len(trip)))
+    return rows
+
+
+def render_loops(rows):
+    lines = ["# loops of the generated gfx950 code that load from global memory (scripts/kernel_resources.py --loops)",
+             "# loads / stores / s_waitcnt vmcnt(0) / s_waitcnt vmcnt(n > 0) per trip; few loads with a full wait per trip = one serial round trip per trip",
+             f"{'kernel':50s} {'loop':>10s} {'depth':>5s} {'loads':>6s} {'stores':>6s} {'wait0':>6s} {'waitN':>6s} {'instr':>6s}"]
+    for r in rows:
+        lines.append(f"{r['kernel'][:50]:50s} {r['loop']:>10s} {r['depth']:5d} {r['loads']:6d} {r['stores']:6d} {r['full_waits']:6d} {r['partial_waits']:6d} {r['instructions']:6d}")
+    return "\n".join(lines) + "\n"
+
+
+def isa_census():
+    """{demangled short kernel name: counts} of the generated assembly of every source."""
+    out = {}
+    if True:
+        if True:
+            for src, name, body in kernel_bodies():
                 row = dict(source=src, instructions=len(body))
                 for key, pattern in ISA_COUNTS:
                     row[key] = sum(1 for c in body if re.search(pattern, c))
                 row["ld_nt"] = sum(1 for c in body if re.match(r"global_load", c) and re.search(r"\bnt\b", c))
                 row["st_nt"] = sum(1 for c in body if re.match(r"global_store", c) and re.search(r"\bnt\b", c))
-                out[short(names[mangled])] = row
+                out[name] = row
     return out
 
 
@@ -155,6 +214,8 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--isa", action="store_true")
     ap.add_argument("--isa-out", default=None)
+    ap.add_argument("--loops", action="store_true")
+    ap.add_argument("--loops-out", default=None)
     args = ap.parse_args()
     text = render(collect())
     if args.out:
@@ -165,6 +226,12 @@ def main():
         text = render_isa(isa_census())
         if args.isa_out:
             with open(args.isa_out, "w") as f:
+                f.write(text)
+        sys.stdout.write(text)
+    if args.loops or args.loops_out:
+        text = render_loops(loop_census())
+        if args.loops_out:
+            with open(args.loops_out, "w") as f:
                 f.write(text)
         sys.stdout.write(text)
 

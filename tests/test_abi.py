@@ -377,3 +377,31 @@ def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
     with open(os.path.join(root, "profiles", "r4_kernel_isa_census.txt")) as f:
         committed = f.read()
     assert committed == kernel_resources.render_isa(census), "profiles/r4_kernel_isa_census.txt is stale: python scripts/kernel_resources.py --isa-out ..."
+
+
+def test_loop_census_kernels_e_and_f_keep_several_loads_in_flight_per_trip():
+    """The loops of the generated code that read global memory (scripts/kernel_resources.py --loops, no GPU): since the staged-load
+    rewrite every vector loop of kernel E issues the 16-byte loads of four sweeps per trip (8 / 16 / 20 loads for forward /
+    backward / second order) and every row or column walk of kernel F at least four loads per operand -- the load-use-store trips
+    of rounds 3-4 (one or two loads, then a full wait) cost one serial memory round trip each at the attack's batch-1 sizes."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    try:
+        import kernel_resources
+    finally:
+        sys.path.pop(0)
+    rows = kernel_resources.loop_census()
+    widest = {}
+    for r in rows:
+        widest[r["kernel"]] = max(widest.get(r["kernel"], 0), r["loads"])
+    assert widest["bn_eval_fwd_kernel"] >= 8 and widest["bn_eval_bwd_kernel"] >= 16 and widest["bn_eval_bwd_bwd_kernel"] >= 20, widest
+    for r in rows:
+        if r["kernel"].startswith("ln_"):
+            assert r["loads"] >= 4, r
+        if r["kernel"].startswith("gm_fwd_kernel"):
+            assert r["loads"] >= 10 and r["full_waits"] == 0, r  # kernel A forward: eight staged 16-byte loads + the row bookkeeping
+    with open(os.path.join(root, "profiles", "r4_kernel_loop_census.txt")) as f:
+        committed = f.read()
+    assert committed == kernel_resources.render_loops(rows), "profiles/r4_kernel_loop_census.txt is stale: python scripts/kernel_resources.py --loops-out ..."
