@@ -401,7 +401,7 @@ def test_loop_census_kernels_e_and_f_keep_several_loads_in_flight_per_trip():
         if r["kernel"].startswith("ln_"):
             assert r["loads"] >= 4, r
         if r["kernel"].startswith("gm_fwd_kernel"):
-            assert r["loads"] >= 10 and r["full_waits"] <= 2, r  # kernel A forward: eight staged 16-byte loads per chunk + the chunk record
+            assert r["loads"] >= 10 and r["full_waits"] <= 3, r  # kernel A forward: eight staged 16-byte loads per chunk (+ the chunk record)
     with open(os.path.join(root, "profiles", "r4_kernel_loop_census.txt")) as f:
         committed = f.read()
     assert committed == kernel_resources.render_loops(rows), "profiles/r4_kernel_loop_census.txt is stale: python scripts/kernel_resources.py --loops-out ..."
