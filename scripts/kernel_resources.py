@@ -94,8 +94,14 @@ ISA_COUNTS = [("ld128", r"global_load_dwordx4"), ("ld64", r"global_load_dwordx2"
               ("mfma", r"v_mfma|v_smfmac"), ("scratch", r"scratch_(load|store)|buffer_(load|store)[a-z0-9_]* .*offen")]
 
 
-def kernel_bodies(keep_labels=False):
-    """[(source, demangled short name, [assembly lines])] from `hipcc -S --cuda-device-only` of every source."""
+_RAW_BODIES = None
+
+
+def _raw_bodies():
+    """[(source, demangled short name, [raw assembly lines])] from `hipcc -S --cuda-device-only` of every source; compiled once per process."""
+    global _RAW_BODIES
+    if _RAW_BODIES is not None:
+        return _RAW_BODIES
     from breaching_amd import build
 
     flags = [f for f in build.FLAGS if f not in ("-shared", "-fPIC")]
@@ -118,16 +124,22 @@ def kernel_bodies(keep_labels=False):
                         continue
                     if line.startswith(".Lfunc_end"):
                         current = None
-                    elif current is not None:
-                        if keep_labels:
-                            if line.strip():
-                                bodies[current].append(line.rstrip())
-                            continue
-                        code = line.split(";")[0].strip()
-                        if code and not code.startswith("."):
-                            bodies[current].append(code)
+                    elif current is not None and line.strip():
+                        bodies[current].append(line.rstrip())
             names = demangle(list(bodies))
             out.extend((src, short(names[mangled]), body) for mangled, body in bodies.items())
+    _RAW_BODIES = out
+    return out
+
+
+def kernel_bodies(keep_labels=False):
+    """[(source, kernel, lines)]: the raw lines (labels, block annotations) or only the instructions."""
+    if keep_labels:
+        return _raw_bodies()
+    out = []
+    for src, name, lines in _raw_bodies():
+        code = [c for c in (line.split(";")[0].strip() for line in lines) if c and not c.startswith(".")]
+        out.append((src, name, code))
     return out
 
 
