@@ -51,8 +51,8 @@ __device__ __forceinline__ float4 mt_elem4(const float4& a, const float4& b, con
                      mt_elem<OP>(a.w, b.w, c.w, k0, k1));
 }
 
-// One chunk, one workgroup.  Every thread issues all of its 16-byte loads (BH_GM_CHUNK / 4 / kBlock per list = 4) before
-// the first use, then computes and stores: 12 loads in flight per thread for the three-operand forms.  HAS_A is resolved
+// One chunk, one workgroup.  On a full chunk every thread issues all of its 16-byte loads (BH_GM_CHUNK / 4 / kBlock per list = 4)
+// before the first use, then computes and stores: 12 loads in flight per thread for the three-operand forms.  HAS_A is resolved
 // per workgroup by the caller -- with the null test inside the loop (`a4 ? a4[i] : zero`, rounds 2-3) the compiler
 // scalarised the float4 into four branch-guarded dword loads per operand (profiles/r4_kernel_isa_census.txt).
 constexpr int kMtIters = BH_GM_CHUNK / 4 / kBlock;
@@ -77,27 +77,32 @@ __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const floa
                                          float* __restrict__ o, int len, float k0, float k1) {
   constexpr bool needs_b = OP != kScale, needs_c = OP == kAxpyMinus || OP == kPatch;
   const int tid = threadIdx.x;
-  const int n4 = len >> 2;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4* __restrict__ a4 = reinterpret_cast<const float4*>(a);
   const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b);
   const float4* __restrict__ c4 = reinterpret_cast<const float4*>(c);
   float4* __restrict__ o4 = reinterpret_cast<float4*>(o);
-  float4 av[kMtIters], bv[kMtIters], cv[kMtIters];
+  if (len == BH_GM_CHUNK) {
+    // Full chunk (all but the last chunk of a tensor), uniform over the workgroup: no per-access guard, every 16-byte load of
+    // every operand issued before the first use -- the shape of kernel A's backward (gm_kernels.hip, gm_bwd_kernel).  With the
+    // `i < n4` guard around each load (round 4) the same bytes took 1.5x as long as that kernel.
+    float4 av[kMtIters], bv[kMtIters], cv[kMtIters];
 #pragma unroll
-  for (int j = 0; j < kMtIters; ++j) {
-    const int i = tid + j * kBlock;
-    av[j] = bv[j] = cv[j] = zero;
-    if (i < n4) {
-      if constexpr (HAS_A) av[j] = mt_load<NT>(a4 + i);
-      if constexpr (needs_b) bv[j] = mt_load<NT>(b4 + i);
-      if constexpr (needs_c) cv[j] = mt_load<NT>(c4 + i);
-    }
+    for (int j = 0; j < kMtIters; ++j) av[j] = HAS_A ? mt_load<NT>(a4 + tid + j * kBlock) : zero;
+#pragma unroll
+    for (int j = 0; j < kMtIters; ++j) bv[j] = needs_b ? mt_load<NT>(b4 + tid + j * kBlock) : zero;
+#pragma unroll
+    for (int j = 0; j < kMtIters; ++j) cv[j] = needs_c ? mt_load<NT>(c4 + tid + j * kBlock) : zero;
+#pragma unroll
+    for (int j = 0; j < kMtIters; ++j) o4[tid + j * kBlock] = mt_elem4<OP>(av[j], bv[j], cv[j], k0, k1);
+    return;
   }
-#pragma unroll
-  for (int j = 0; j < kMtIters; ++j) {
-    const int i = tid + j * kBlock;
-    if (i < n4) o4[i] = mt_elem4<OP>(av[j], bv[j], cv[j], k0, k1);
+  const int n4 = len >> 2;
+  for (int i = tid; i < n4; i += kBlock) {
+    const float4 av = HAS_A ? mt_load<NT>(a4 + i) : zero;
+    const float4 bv = needs_b ? mt_load<NT>(b4 + i) : zero;
+    const float4 cv = needs_c ? mt_load<NT>(c4 + i) : zero;
+    o4[i] = mt_elem4<OP>(av, bv, cv, k0, k1);
   }
   const int tail = len & 3;
   if (tid < tail) {

@@ -153,6 +153,126 @@ __global__ __launch_bounds__(kBlock) void tv_norm_kernel(const float* __restrict
   }
 }
 
+// Four horizontally adjacent pixels per thread (W a multiple of 4, 16-byte aligned planes): per colour plane the centre, south and
+// north rows arrive as one 16-byte load each plus the four edge scalars (west, east, south-west, north-east of the quad) -- 3 x
+// ld128 + 4 x ld32 instead of 28 x ld32 -- and the three output planes leave as 16-byte stores.  Per pixel the arithmetic is the
+// scalar kernel's (same Plane7, same plane_grad), so the gradient is bit-identical; the value differs only in the order of the fp64
+// adds.  Instantiated for p = q = 1 only (every shipped TV configuration but modern.yaml / legacy.yaml; the general exponents inline
+// powf a dozen times per pixel and stay on the scalar kernel).  At BASELINE configs[2] (8 x 3 x 224 x 224) the scalar kernel moved 9.6 MB in 8.2-8.5 us (profiles/r4_config3_*).
+struct Rows {
+  float c[6];  // row i: west, the four centres, east
+  float s[5];  // row i+1: south-west, the four souths
+  float n[5];  // row i-1: the four norths, north-east of the last
+};
+
+__device__ __forceinline__ Rows load_rows(const float* __restrict__ u, int i, int j, int H, int W) {
+  Rows r;
+  const int64_t o = (int64_t)i * W + j;
+  const bool has_s = i + 1 < H, has_n = i > 0, has_w = j > 0, has_e = j + 4 < W;
+  // Every load is unconditional (an out-of-image neighbour reads a clamped, valid address and is zeroed in registers): a
+  // `cond ? *p : zero` on a float4 is scalarised by the compiler into four guarded dword loads (profiles/r4_kernel_isa_census.txt,
+  // the round-2/3 multi-tensor kernel), and ten independent loads per plane are in flight together this way.
+  const float4 c4 = *reinterpret_cast<const float4*>(u + o);
+  const float4 s4 = *reinterpret_cast<const float4*>(u + o + (has_s ? W : 0));
+  const float4 n4 = *reinterpret_cast<const float4*>(u + o - (has_n ? W : 0));
+  const float w = u[o - (has_w ? 1 : 0)];
+  const float e = u[o + (has_e ? 4 : 3)];
+  const float sw = u[o + ((has_w && has_s) ? W - 1 : 0)];
+  const float ne = u[o - ((has_n && has_e) ? W - 4 : 0)];
+  r.c[0] = has_w ? w : 0.f;  // zero padding of the conv (regularizers.py:142-144, padding=1)
+  r.c[5] = has_e ? e : 0.f;
+  r.s[0] = (has_w && has_s) ? sw : 0.f;
+  r.n[4] = (has_n && has_e) ? ne : 0.f;
+  r.c[1] = c4.x, r.c[2] = c4.y, r.c[3] = c4.z, r.c[4] = c4.w;
+  r.s[1] = has_s ? s4.x : 0.f, r.s[2] = has_s ? s4.y : 0.f, r.s[3] = has_s ? s4.z : 0.f, r.s[4] = has_s ? s4.w : 0.f;
+  r.n[0] = has_n ? n4.x : 0.f, r.n[1] = has_n ? n4.y : 0.f, r.n[2] = has_n ? n4.z : 0.f, r.n[3] = has_n ? n4.w : 0.f;
+  return r;
+}
+
+__device__ __forceinline__ Plane7 pixel_of(const Rows& r, int k) {
+  return Plane7{r.c[k + 1], r.s[k + 1], r.c[k + 2], r.n[k], r.n[k + 1], r.c[k], r.s[k]};
+}
+
+struct TvCoefs {
+  float tv_coef, p, q, eps, norm_grad_coef, norm_p;
+};
+
+// Pixel K of a quad: gradient of the three colour planes, value terms into the two fp64 accumulators (same statements as the scalar
+// kernel's loop body).
+template <bool OPP, int K>
+__device__ __forceinline__ void quad_pixel(const Rows& rr, const Rows& rg, const Rows& rb, bool has_n, bool has_w, const TvCoefs& k,
+                                           float& gr, float& gg, float& gb, double& acc_tv, double& acc_norm) {
+  const Plane7 r = pixel_of(rr, K), g = pixel_of(rg, K), bl = pixel_of(rb, K);
+  float value = 0.f;
+  gr = plane_grad<true>(r, has_n, has_w, k.p, k.q, k.eps, value);
+  gg = plane_grad<true>(g, has_n, has_w, k.p, k.q, k.eps, value);
+  gb = plane_grad<true>(bl, has_n, has_w, k.p, k.q, k.eps, value);
+  if constexpr (OPP) {
+    const float o1 = plane_grad<true>(sub7(r, g), has_n, has_w, k.p, k.q, k.eps, value);
+    const float o2 = plane_grad<true>(sub7(r, bl), has_n, has_w, k.p, k.q, k.eps, value);
+    const float o3 = plane_grad<true>(sub7(g, bl), has_n, has_w, k.p, k.q, k.eps, value);
+    gr += o1 + o2;
+    gg += o3 - o1;
+    gb -= o2 + o3;
+  }
+  gr *= k.tv_coef;
+  gg *= k.tv_coef;
+  gb *= k.tv_coef;
+  acc_tv += (double)value;
+  if (k.norm_grad_coef != 0.f) {
+    float xp0, xp1, xp2;
+    if (k.norm_p == 2.f) {
+      xp0 = r.c * r.c, xp1 = g.c * g.c, xp2 = bl.c * bl.c;
+      gr = fmaf(k.norm_grad_coef, r.c, gr);
+      gg = fmaf(k.norm_grad_coef, g.c, gg);
+      gb = fmaf(k.norm_grad_coef, bl.c, gb);
+    } else {
+      xp0 = powf(r.c, k.norm_p), xp1 = powf(g.c, k.norm_p), xp2 = powf(bl.c, k.norm_p);
+      gr += k.norm_grad_coef * powf(r.c, k.norm_p - 1.f);
+      gg += k.norm_grad_coef * powf(g.c, k.norm_p - 1.f);
+      gb += k.norm_grad_coef * powf(bl.c, k.norm_p - 1.f);
+    }
+    acc_norm += (double)xp0 + (double)xp1 + (double)xp2;
+  }
+}
+
+template <bool OPP, int THREADS>
+__global__ __launch_bounds__(THREADS) void tv_norm_vec4_kernel(const float* __restrict__ x, int B, int H, int W, float tv_coef,
+                                                               float p, float q, float eps, float norm_val_coef,
+                                                               float norm_grad_coef, float norm_p, float* __restrict__ grad,
+                                                               double* __restrict__ partials) {
+  __shared__ double lds[(THREADS / bh::kWave) * 2];
+  const int64_t plane = (int64_t)H * W;
+  const int W4 = W >> 2;
+  const int64_t quads_per_image = (int64_t)H * W4;
+  const int64_t total = (int64_t)B * quads_per_image;
+  const TvCoefs k{tv_coef, p, q, eps, norm_grad_coef, norm_p};
+  double acc_tv = 0.0, acc_norm = 0.0;
+  for (int64_t idx = (int64_t)blockIdx.x * THREADS + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * THREADS) {
+    const int b = (int)(idx / quads_per_image);
+    const int64_t rem = idx - (int64_t)b * quads_per_image;
+    const int i = (int)(rem / W4), j = (int)(rem - (int64_t)i * W4) << 2;
+    const float* __restrict__ xb = x + (int64_t)b * 3 * plane;
+    const Rows rr = load_rows(xb, i, j, H, W), rg = load_rows(xb + plane, i, j, H, W), rb = load_rows(xb + 2 * plane, i, j, H, W);
+    const bool has_n = i > 0;
+    float4 out_r, out_g, out_b;
+    quad_pixel<OPP, 0>(rr, rg, rb, has_n, j > 0, k, out_r.x, out_g.x, out_b.x, acc_tv, acc_norm);
+    quad_pixel<OPP, 1>(rr, rg, rb, has_n, true, k, out_r.y, out_g.y, out_b.y, acc_tv, acc_norm);
+    quad_pixel<OPP, 2>(rr, rg, rb, has_n, true, k, out_r.z, out_g.z, out_b.z, acc_tv, acc_norm);
+    quad_pixel<OPP, 3>(rr, rg, rb, has_n, true, k, out_r.w, out_g.w, out_b.w, acc_tv, acc_norm);
+    float* __restrict__ gbase = grad + (int64_t)b * 3 * plane + (int64_t)i * W + j;
+    *reinterpret_cast<float4*>(gbase) = out_r;
+    *reinterpret_cast<float4*>(gbase + plane) = out_g;
+    *reinterpret_cast<float4*>(gbase + 2 * plane) = out_b;
+  }
+  double v[2] = {acc_tv, acc_norm};
+  bh::block_sum<2>(v, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * BH_PRIOR_PARTIAL_STRIDE + 0] = v[0] * (double)tv_coef;
+    partials[blockIdx.x * BH_PRIOR_PARTIAL_STRIDE + 1] = v[1] * (double)norm_val_coef;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel D: all BatchNorm inputs of a model in ONE launch per stage
 // ---------------------------------------------------------------------------------------------------------------
@@ -555,8 +675,6 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
   if (x == nullptr || grad_out == nullptr || partials_dev == nullptr || B <= 0 || H <= 0 || W <= 0) return BH_EINVAL;
   if (norm_scale != 0.f && norm_p == 0.f) return BH_EINVAL;
   const int64_t pixels = (int64_t)B * H * W;
-  int64_t blocks = (pixels + kBlock - 1) / kBlock;
-  const int grid = (int)(blocks < BH_PRIOR_MAX_GRID ? blocks : BH_PRIOR_MAX_GRID);
   const int groups = double_opponents ? 6 : 3;
   // mean over [B, groups, H, W] (regularizers.py:147) / mean over [B, 3, H, W] (:197)
   const float tv_coef = (float)((double)tv_scale / ((double)pixels * groups));
@@ -564,14 +682,36 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
   const float norm_grad_coef = norm_scale != 0.f ? (float)((double)norm_scale / ((double)pixels * 3)) : 0.f;
   const bool pq1 = inner_exp == 1.f && outer_exp == 1.f;
   hipStream_t st = bh::as_stream(stream);
+  // 16-byte path: every row of every plane starts on a 16-byte boundary.  Small images (fewer quads than one 256-thread workgroup
+  // per CU would take) run one wavefront per workgroup so that B = 1 at 224 x 224 still spreads over 196 CUs.
+  const bool vec4 = pq1 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_out)) & 15u) == 0;
+  int grid;
+  if (vec4) {
+    const int64_t quads = pixels >> 2;
+    const bool wide = quads >= (int64_t)256 * kBlock;
+    const int threads = wide ? kBlock : bh::kWave;
+    const int64_t blocks = (quads + threads - 1) / threads;
+    grid = (int)(blocks < BH_PRIOR_MAX_GRID ? blocks : BH_PRIOR_MAX_GRID);
+#define BH_TV_LAUNCH(OPP, THREADS)                                                                                     \
+  hipLaunchKernelGGL((tv_norm_vec4_kernel<OPP, THREADS>), dim3(grid), dim3(THREADS), 0, st, x, B, H, W, tv_coef,       \
+                     inner_exp, outer_exp, eps, norm_val_coef, norm_grad_coef, norm_p, grad_out, partials_dev)
+    if (wide && double_opponents) BH_TV_LAUNCH(true, kBlock);
+    else if (wide) BH_TV_LAUNCH(false, kBlock);
+    else if (double_opponents) BH_TV_LAUNCH(true, bh::kWave);
+    else BH_TV_LAUNCH(false, bh::kWave);
+#undef BH_TV_LAUNCH
+  } else {
+    const int64_t blocks = (pixels + kBlock - 1) / kBlock;
+    grid = (int)(blocks < BH_PRIOR_MAX_GRID ? blocks : BH_PRIOR_MAX_GRID);
 #define BH_TV_LAUNCH(PQ1, OPP)                                                                                         \
   hipLaunchKernelGGL((tv_norm_kernel<PQ1, OPP>), dim3(grid), dim3(kBlock), 0, st, x, B, H, W, tv_coef, inner_exp,     \
                      outer_exp, eps, norm_val_coef, norm_grad_coef, norm_p, grad_out, partials_dev)
-  if (pq1 && !double_opponents) BH_TV_LAUNCH(true, false);
-  else if (pq1) BH_TV_LAUNCH(true, true);
-  else if (!double_opponents) BH_TV_LAUNCH(false, false);
-  else BH_TV_LAUNCH(false, true);
+    if (pq1 && !double_opponents) BH_TV_LAUNCH(true, false);
+    else if (pq1) BH_TV_LAUNCH(true, true);
+    else if (!double_opponents) BH_TV_LAUNCH(false, false);
+    else BH_TV_LAUNCH(false, true);
 #undef BH_TV_LAUNCH
+  }
   const int rc = bh::launch_status();
   return rc != 0 ? rc : grid;
 }

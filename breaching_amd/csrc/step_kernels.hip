@@ -103,55 +103,114 @@ __global__ __launch_bounds__(kBlock) void grad_norm_finalize_kernel(Word* __rest
 // The fused step.  fp32 arithmetic follows torch.optim's single-tensor Adam update term by term:
 //   exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1-beta2)
 //   denom = (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps); param.addcdiv_(exp_avg, denom, value=-lr/bc1)
+struct StepScalars {
+  float step_size, bc2_sqrt, decay, noise_coef, clip_mul, soft, w1, w2, beta2, eps;
+  bool improved;
+};
+
+__device__ __forceinline__ StepScalars step_scalars(const Word* __restrict__ st, const double* __restrict__ sched,
+                                                    const bh_step_params& P, bool has_noise) {
+  StepScalars k;
+  const int it = st[BH_STATE_IT].i;
+  k.improved = st[BH_STATE_IMPROVED].i != 0;
+  const double* row = sched + (int64_t)it * BH_SCHED_STRIDE;
+  k.step_size = (float)row[0];
+  k.bc2_sqrt = (float)row[1];
+  k.decay = (float)row[2];
+  k.noise_coef = has_noise ? (float)((double)P.langevin * row[3]) : 0.f;
+  k.clip_mul = 1.f;
+  if (P.grad_clip >= 0.f) {  // negative: clipping off (optim.grad_clip = None)
+    const float gn = st[BH_STATE_GNORM].f;
+    if (gn > P.grad_clip) k.clip_mul = P.grad_clip / (gn + 1e-6f);  // :173-174
+  }
+  // soft sign factor (:176-180): python evaluates 1 - iteration / max_iterations in double
+  k.soft = (float)(1.0 - (double)it / (double)P.max_iterations);
+  // torch passes `1 - beta` (evaluated in double) and `beta2`, `eps` as Python scalars that become fp32 in the kernels
+  k.w1 = (float)(1.0 - P.beta1);
+  k.w2 = (float)(1.0 - P.beta2);
+  k.beta2 = (float)P.beta2;
+  k.eps = (float)P.eps;
+  return k;
+}
+
+// One element: gr = assembled gradient (objective + prior + noise); lo / hi = the box of its channel.
+__device__ __forceinline__ void step_elem(const StepScalars& k, const bh_step_params& P, float gr, float lo, float hi, float& xi,
+                                          float& mi, float& vi) {
+  gr *= k.clip_mul;
+  if (P.sign_mode == BH_SIGN_HARD) {
+    gr = bh::sgnf(gr);  // :181-182
+  } else if (P.sign_mode == BH_SIGN_SOFT) {
+    gr = tanhf(gr * k.soft) / k.soft;  // :180
+  }
+  if (P.decoupled_wd) xi *= k.decay;
+  mi = fmaf(k.w1, gr - mi, mi);
+  vi = fmaf(k.w2 * gr, gr, vi * k.beta2);
+  const float denom = sqrtf(vi) / k.bc2_sqrt + k.eps;
+  xi = xi - (k.step_size * mi) / denom;
+  // :117-118  max(min(x, hi), lo); torch.min / torch.max propagate NaN, fminf / fmaxf would swallow it
+  if (P.boxed) xi = (xi != xi) ? xi : fmaxf(fminf(xi, hi), lo);
+}
+
 __global__ __launch_bounds__(kBlock) void candidate_step_kernel(const Word* __restrict__ st, const double* __restrict__ sched,
                                                                 bh_step_params P, float* __restrict__ x,
                                                                 const float* __restrict__ g,
                                                                 const float* __restrict__ g_reg,
                                                                 const float* __restrict__ noise, float* __restrict__ m,
                                                                 float* __restrict__ v, float* __restrict__ best) {
-  const int it = st[BH_STATE_IT].i;
-  const bool improved = st[BH_STATE_IMPROVED].i != 0;
-  const double* row = sched + (int64_t)it * BH_SCHED_STRIDE;
-  const float step_size = (float)row[0];
-  const float bc2_sqrt = (float)row[1];
-  const float decay = (float)row[2];
-  const float noise_coef = noise ? (float)((double)P.langevin * row[3]) : 0.f;
-  float clip_mul = 1.f;
-  if (P.grad_clip >= 0.f) {  // negative: clipping off (optim.grad_clip = None)
-    const float gn = st[BH_STATE_GNORM].f;
-    if (gn > P.grad_clip) clip_mul = P.grad_clip / (gn + 1e-6f);  // :173-174
-  }
-  // soft sign factor (:176-180): python evaluates 1 - iteration / max_iterations in double
-  const float soft = (float)(1.0 - (double)it / (double)P.max_iterations);
-  // torch passes `1 - beta` (evaluated in double) and `beta2`, `eps` as Python scalars that become fp32 in the kernels
-  const float w1 = (float)(1.0 - P.beta1);
-  const float w2 = (float)(1.0 - P.beta2);
-  const float beta2 = (float)P.beta2;
-  const float eps = (float)P.eps;
-
+  const StepScalars k = step_scalars(st, sched, P, noise != nullptr);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < P.n; i += (int64_t)gridDim.x * kBlock) {
-    float gr = effective_grad(g, g_reg, noise, noise_coef, i);
-    gr *= clip_mul;
-    if (P.sign_mode == BH_SIGN_HARD) {
-      gr = bh::sgnf(gr);  // :181-182
-    } else if (P.sign_mode == BH_SIGN_SOFT) {
-      gr = tanhf(gr * soft) / soft;  // :180
-    }
+    const float gr = effective_grad(g, g_reg, noise, k.noise_coef, i);
     float xi = x[i], mi = m[i], vi = v[i];
-    if (P.decoupled_wd) xi *= decay;
-    mi = fmaf(w1, gr - mi, mi);
-    vi = fmaf(w2 * gr, gr, vi * beta2);
-    const float denom = sqrtf(vi) / bc2_sqrt + eps;
-    xi = xi - (step_size * mi) / denom;
-    if (P.boxed) {  // :117-118  max(min(x, hi), lo)
-      const int c = (int)((i / P.plane) % P.channels);
-      // torch.min / torch.max propagate NaN, fminf / fmaxf would swallow it
-      xi = (xi != xi) ? xi : fmaxf(fminf(xi, P.hi[c]), P.lo[c]);
-    }
+    const int c = P.boxed ? (int)((i / P.plane) % P.channels) : 0;
+    step_elem(k, P, gr, P.lo[c], P.hi[c], xi, mi, vi);
     x[i] = xi;
     m[i] = mi;
     v[i] = vi;
-    if (improved) best[i] = xi;  // :119-121 (clone taken after step + projection)
+    if (k.improved) best[i] = xi;  // :119-121 (clone taken after step + projection)
+  }
+}
+
+// 16-byte variant: n and the channel plane are multiples of 4 and every buffer is 16-byte aligned, so a float4 never straddles
+// a channel and the box of its four elements is one (lo, hi) pair, looked up once.  All loads of a float4 group are issued before
+// the first use.  Element arithmetic = step_elem, i.e. bit-identical to the scalar kernel.  (At BASELINE configs[2], 8 x 3 x 224 x
+// 224, the scalar kernel moved ~43-48 MB in 11.4-11.9 us with 4-byte accesses, profiles/r4_kernel_isa_census.txt.)
+__global__ __launch_bounds__(kBlock) void candidate_step_vec4_kernel(const Word* __restrict__ st, const double* __restrict__ sched,
+                                                                     bh_step_params P, float* __restrict__ x,
+                                                                     const float* __restrict__ g,
+                                                                     const float* __restrict__ g_reg,
+                                                                     const float* __restrict__ noise, float* __restrict__ m,
+                                                                     float* __restrict__ v, float* __restrict__ best) {
+  const StepScalars k = step_scalars(st, sched, P, noise != nullptr);
+  const int64_t n4 = P.n >> 2, plane4 = P.plane >> 2;
+  float4* __restrict__ x4 = reinterpret_cast<float4*>(x);
+  float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
+  float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
+  float4* __restrict__ b4 = reinterpret_cast<float4*>(best);
+  const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+  const float4* __restrict__ r4 = reinterpret_cast<const float4*>(g_reg);
+  const float4* __restrict__ z4 = reinterpret_cast<const float4*>(noise);
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
+    const float4 gv = g4[i];
+    const float4 rv = r4 ? r4[i] : zero;
+    const float4 zv = z4 ? z4[i] : zero;
+    float4 xv = x4[i], mv = m4[i], vv = v4[i];
+    const int c = P.boxed ? (int)((i / plane4) % P.channels) : 0;
+    const float lo = P.lo[c], hi = P.hi[c];
+    float ge[4] = {gv.x, gv.y, gv.z, gv.w};
+    if (r4) ge[0] += rv.x, ge[1] += rv.y, ge[2] += rv.z, ge[3] += rv.w;
+    if (z4) {  // optimization_based_attack.py:167-170
+      ge[0] = fmaf(k.noise_coef, zv.x, ge[0]), ge[1] = fmaf(k.noise_coef, zv.y, ge[1]);
+      ge[2] = fmaf(k.noise_coef, zv.z, ge[2]), ge[3] = fmaf(k.noise_coef, zv.w, ge[3]);
+    }
+    step_elem(k, P, ge[0], lo, hi, xv.x, mv.x, vv.x);
+    step_elem(k, P, ge[1], lo, hi, xv.y, mv.y, vv.y);
+    step_elem(k, P, ge[2], lo, hi, xv.z, mv.z, vv.z);
+    step_elem(k, P, ge[3], lo, hi, xv.w, mv.w, vv.w);
+    x4[i] = xv;
+    m4[i] = mv;
+    v4[i] = vv;
+    if (k.improved) b4[i] = xv;
   }
 }
 
@@ -203,11 +262,21 @@ int bh_candidate_step(const void* state_dev, const double* sched_dev, const bh_s
   if (P.boxed && (P.channels <= 0 || P.channels > 4 || P.plane <= 0)) return BH_EINVAL;
   if (P.langevin > 0.f && noise == nullptr) return BH_EINVAL;
   if (P.sign_mode < BH_SIGN_NONE || P.sign_mode > BH_SIGN_SOFT) return BH_EINVAL;
-  int64_t blocks = (P.n + kBlock - 1) / kBlock;
+  if (P.langevin <= 0.f) noise = nullptr;
+  const uintptr_t align = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(g_reg) |
+                          reinterpret_cast<uintptr_t>(noise) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) |
+                          reinterpret_cast<uintptr_t>(best);
+  const bool vec4 = (P.n & 3) == 0 && (align & 15u) == 0 && (!P.boxed || (P.plane & 3) == 0);
+  const int64_t units = vec4 ? P.n >> 2 : P.n;
+  int64_t blocks = (units + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(candidate_step_kernel, dim3((int)blocks), dim3(kBlock), 0, bh::as_stream(stream),
-                     static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, P.langevin > 0.f ? noise : nullptr,
-                     m, v, best);
+  if (vec4)
+    hipLaunchKernelGGL(candidate_step_vec4_kernel, dim3((int)blocks), dim3(kBlock), 0, bh::as_stream(stream),
+                       static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, noise, m, v, best);
+  else
+    hipLaunchKernelGGL(candidate_step_kernel, dim3((int)blocks), dim3(kBlock), 0, bh::as_stream(stream),
+                       static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, noise, m, v,
+                       best);
   return bh::launch_status();
 }
 

@@ -932,6 +932,83 @@ def golden_tag_bert_base():
     np.savez_compressed(os.path.join(GOLDEN, "attack_tag_bert_base.npz"), **out)
 
 
+# ---- BASELINE configs[4] at its STATED schedule: tag.yaml untouched (1 000 iterations, warm-up 50, linear decay, clip 1.0) ----
+TAG_LONG_DIR = os.path.join(HERE, "_long")
+
+
+def _tag_bert_base_1000_worker(idx, out_path, threads=3, iters=None):
+    """One run of the reference's OptimizationJointAttacker (optimization_with_label_attack.py:89-205) on BERT-base, sequence
+    length 32, with tag.yaml exactly as shipped.  idx 0 = the nominal run (torch.manual_seed(3) before `reconstruct`, as in
+    golden_tag_bert_base); idx 1 = the same seed with the drawn embedding start moved by <= 16 ulp (the bound
+    `_initialize_data` of the attacker INSTANCE is wrapped from outside; no reference file is touched): the reference's own
+    reproducibility envelope for this smooth (AdamW, no sign) trajectory."""
+    import time as _time
+
+    breaching = import_reference(preload_transformers=True)
+    from breaching_amd.cases import build_text_case, parameter_checksum
+
+    torch.set_num_threads(threads)
+    case = build_text_case(full_size=True, seq_len=32)
+    over = ["optim.callback=100"] if iters is None else [f"optim.max_iterations={iters}", "optim.callback=100"]
+    cfg = _cfg("tag", over)
+    if iters is None:
+        assert cfg.optim.max_iterations == 1000 and cfg.optim.warmup == 50 and cfg.optim.step_size_decay == "linear"
+        assert cfg.optim.grad_clip == 1.0 and cfg.optim.optimizer == "bert-adam" and cfg.optim.step_size == 0.05
+    attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+    if idx > 0:
+        inner_init = attacker._initialize_data
+        calls = [0]
+        gen = torch.Generator().manual_seed(LONG_SEED + idx)
+
+        def perturbed_init(shape):
+            out = inner_init(shape)
+            calls[0] += 1
+            if calls[0] == 2:  # 1 = label template (:42-49), 2 = the trial's embedding candidate (:98), 3 = its labels (:99)
+                with torch.no_grad():
+                    out.copy_(_ulp_perturb(out.detach(), 16, gen))
+            return out
+
+        attacker._initialize_data = perturbed_init
+    inner_compute = attacker._compute_objective
+    t0 = _time.time()
+
+    def timed_compute(candidate, labels, rec_model, optimizer, shared_data, iteration):
+        if iteration % 50 == 0 and iteration > 0:
+            print(f"  tag run {idx}: iteration {iteration}, {(_time.time() - t0) / iteration:.3f} s/it", flush=True)
+        return inner_compute(candidate, labels, rec_model, optimizer, shared_data, iteration)
+
+    attacker._compute_objective = timed_compute
+    torch.manual_seed(3)
+    rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {})
+    out = dict(history=np.asarray(stats["Trial_0_Val"], dtype=np.float32), opt_value=np.float64(stats["opt_value"]),
+               tokens=rec["data"].numpy(), labels=rec["labels"].numpy(), raw_embeddings=rec["raw_embeddings"].numpy(),
+               seconds=np.float64(_time.time() - t0), threads=np.int64(threads))
+    if idx == 0:
+        out.update(n_observed=np.int64(len(case.shared_data[0]["gradients"])), n_parameters=np.int64(sum(1 for _ in case.model.parameters())),
+                   model_checksum=np.float64(parameter_checksum(case.model)), true_tokens=case.true_user_data["data"].numpy(),
+                   seed=np.int64(3), grad_checksum=np.float64(sum(float(g.double().sum()) for g in case.shared_data[0]["gradients"])))
+    np.savez(out_path, **out)
+
+
+def assemble_tag_bert_base_1000():
+    main = dict(np.load(os.path.join(TAG_LONG_DIR, "tag0.npz")))
+    twin = np.load(os.path.join(TAG_LONG_DIR, "tag1.npz"))
+    main.update({f"twin_{k}": twin[k] for k in ("history", "opt_value", "tokens", "labels", "raw_embeddings")})
+    main.update(iterations=np.int64(len(main["history"])), twin_seed=np.int64(LONG_SEED + 1), twin_ulps=np.int64(16))
+    np.savez_compressed(os.path.join(GOLDEN, "attack_tag_bert_base_1000.npz"), **main)
+
+
+def golden_tag_bert_base_1000():
+    """BASELINE configs[4] with tag.yaml untouched: nominal + one 16-ulp twin, run one after the other (finished runs found in
+    oracle/_long/ are kept)."""
+    os.makedirs(TAG_LONG_DIR, exist_ok=True)
+    for idx in (0, 1):
+        path = os.path.join(TAG_LONG_DIR, f"tag{idx}.npz")
+        if not os.path.exists(path):
+            _tag_bert_base_1000_worker(idx, path, threads=int(os.environ.get("GOLDEN_THREADS", "3")))
+    assemble_tag_bert_base_1000()
+
+
 class _LegacyTorchSemantics:
     """Harness-side shim (no reference file is touched) that lets the reference's Pearlmutter objectives run under torch 2.x:
     they were written for torch 1.10, where (a) `torch._foreach_add_/_foreach_sub_` on parameters that require grad did not
@@ -1044,8 +1121,9 @@ STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_sc
              variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg, multiquery=golden_multiquery,
              resnet18_long=golden_resnet18_long, seethrough_b8=golden_seethrough_b8, tag_bert_base=golden_tag_bert_base,
              pearlmutter=golden_pearlmutter, resnet18_24k=golden_resnet18_24k, seethrough_noise=golden_seethrough_noise,
-             resnet18_long_signs=golden_resnet18_long_signs)
-SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base", "resnet18_24k", "seethrough_noise", "resnet18_long_signs")  # hours of CPU: only run when asked for by name
+             resnet18_long_signs=golden_resnet18_long_signs, tag_bert_base_1000=golden_tag_bert_base_1000)
+SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base", "resnet18_24k", "seethrough_noise", "resnet18_long_signs",
+              "tag_bert_base_1000")  # hours of CPU: only run when asked for by name
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
@@ -1053,18 +1131,23 @@ if __name__ == "__main__":
     parser.add_argument("--long-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
     parser.add_argument("--full-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
     parser.add_argument("--full-iters", type=int, default=None, help="(testing the generator) shorter horizon")
+    parser.add_argument("--tag-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
+    parser.add_argument("--threads", type=int, default=2, help="torch CPU threads of a --long-worker / --full-worker run")
     args = parser.parse_args()
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     if args.long_worker is not None:
         _resnet18_long_worker(int(args.long_worker[0]), args.long_worker[1])
         sys.exit(0)
+    if args.tag_worker is not None:
+        _tag_bert_base_1000_worker(int(args.tag_worker[0]), args.tag_worker[1], threads=args.threads, iters=args.full_iters)
+        sys.exit(0)
     if args.full_worker is not None:
         if args.full_iters:
             n = args.full_iters
-            _resnet18_full_worker(int(args.full_worker[0]), args.full_worker[1], iters=n, forced=(2, n // 2, n - 4))
+            _resnet18_full_worker(int(args.full_worker[0]), args.full_worker[1], threads=args.threads, iters=n, forced=(2, n // 2, n - 4))
         else:
-            _resnet18_full_worker(int(args.full_worker[0]), args.full_worker[1])
+            _resnet18_full_worker(int(args.full_worker[0]), args.full_worker[1], threads=args.threads)
         sys.exit(0)
     for name, fn in STEPS.items():
         if (args.only is None and name not in SLOW_STEPS) or args.only == name:

@@ -1,0 +1,64 @@
+# One GPU call = a list of named stages (round 5 replaces the per-call r3_/r4_ scripts by this one file):
+#   /usr/local/graft/bin/gpurun --timeout 1200 -- 'bash scripts/gpu_call.sh r5a kernels ceiling mt stepprior'
+# First argument = tag (prefix of everything written under gpurun_out/), then stages in order.  Every stage runs under its own
+# `timeout`: a hung pass must not eat the GPU budget.  Summaries that are kept are copied to profiles/ by hand.
+TAG=$1; shift
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+B="python $GRAFT_REPO_ROOT/bench.py"
+PREV=$GRAFT_REPO_ROOT/build/libbreach_hip_prev.so
+
+prof() {  # prof <seconds> <name> <pmc-counter or ""> <command...>: rocprofv3 kernel trace (+stats) or one PMC pass, summarised
+  limit=$1; name=${TAG}_$2; counter=$3; shift 3
+  rm -rf /tmp/prof_$name
+  if [ -z "$counter" ]; then
+    (cd /tmp && timeout $limit rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- "$@" > $OUT/${name}_stdout.log 2> $OUT/${name}_stderr.log)
+  else
+    (cd /tmp && timeout $limit rocprofv3 --pmc $counter --output-format csv -d /tmp/prof_$name -- "$@" > $OUT/${name}_stdout.log 2> $OUT/${name}_stderr.log)
+  fi
+  first=$(find /tmp/prof_$name -name "*.csv" | head -1)
+  if [ -n "$first" ]; then
+    dir=$(dirname $first)
+    python scripts/summarize_prof.py $dir $OUT/$name $counter | head -14
+    cp $dir/*kernel_stats.csv $OUT/${name}_rocprofv3_kernel_stats.csv 2>/dev/null
+  fi
+  tail -1 $OUT/${name}_stdout.log | cut -c1-300
+}
+
+smoke()    { timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; tail -1 $OUT/${TAG}_smoke.log | cut -c1-200; }
+kernels()  { timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q > $OUT/${TAG}_gpu_tests_kernels.log 2>&1; tail -3 $OUT/${TAG}_gpu_tests_kernels.log | cut -c1-250; }
+suite()    { timeout 2400 python -m pytest tests -m gpu -x -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -1 $OUT/${TAG}_gpu_tests.log | cut -c1-200; }
+ceiling()  { timeout 300 python scripts/read_ceiling_probe.py --launches 30 > $OUT/${TAG}_read_ceiling_probe.jsonl 2> $OUT/${TAG}_read_ceiling_probe.err; grep -c . $OUT/${TAG}_read_ceiling_probe.jsonl; grep "kernel A" $OUT/${TAG}_read_ceiling_probe.jsonl | cut -c1-400; tail -2 $OUT/${TAG}_read_ceiling_probe.err | cut -c1-300; }
+mt()       { timeout 200 python scripts/mt_kernel_probe.py --prev build/libbreach_mt_prev.so --launches 30 > $OUT/${TAG}_mt_kernel_probe.jsonl 2> $OUT/${TAG}_mt_kernel_probe.err; cut -c1-700 $OUT/${TAG}_mt_kernel_probe.jsonl; tail -2 $OUT/${TAG}_mt_kernel_probe.err | cut -c1-300; }
+stepprior() {
+  timeout 120 python scripts/step_prior_probe.py > $OUT/${TAG}_step_prior_probe.jsonl 2> $OUT/${TAG}_step_prior_probe.err
+  BREACH_HIP_LIB=$PREV timeout 120 python scripts/step_prior_probe.py >> $OUT/${TAG}_step_prior_probe.jsonl 2>> $OUT/${TAG}_step_prior_probe.err
+  cut -c1-330 $OUT/${TAG}_step_prior_probe.jsonl; tail -2 $OUT/${TAG}_step_prior_probe.err | cut -c1-300
+}
+bench_driver() { timeout 600 $B --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_style.json 2> $OUT/${TAG}_bench_driver_style.err; cut -c1-600 $OUT/${TAG}_bench_driver_style.json; tail -2 $OUT/${TAG}_bench_driver_style.err | cut -c1-300; }
+bench_n1()     { timeout 600 $B > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err; cut -c1-300 $OUT/${TAG}_bench_n1.json; }
+bench_4()      { timeout 600 $B --trials-per-gpu 4 --cpu-baseline-iters 0 --no-hbm-resident > $OUT/${TAG}_bench_n1_4trials_in_flight.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_n1_4trials_in_flight.json; }
+bench_8ranks() { timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 20 --warmup 5 > $OUT/${TAG}_bench_8ranks_one_gpu.json 2> $OUT/${TAG}_bench_8ranks_one_gpu.err; tail -1 $OUT/${TAG}_bench_8ranks_one_gpu.json | cut -c1-900; tail -3 $OUT/${TAG}_bench_8ranks_one_gpu.err | cut -c1-300; }
+trace_bench()  {
+  prof 400 bench "" $B --steps 100 --warmup 20 --cpu-baseline-iters 0 --no-span-timing --no-hbm-resident --no-dry-collective
+  trace=$(ls -S $(find /tmp/prof_${TAG}_bench -name "*kernel_trace.csv") | head -1)
+  [ -n "$trace" ] && python scripts/gap_census.py $trace $OUT/${TAG}_1trial_gap_census --iters 60 --skip-tail 45 --label "1 trial, round 5 HEAD" | head -20
+}
+trace5()   { prof 400 config5_bert_tag "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 5; }
+trace3()   { prof 400 config3_resnet50_seethrough "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 3; }
+trace_fedavg() { prof 400 fedavg_resnet50 "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only fedavg; }
+pmc()      {  # pmc <size>: FETCH_SIZE and WRITE_SIZE in separate passes over scripts/pmc_target.py --size <size>
+  prof 200 pmc_fetch_$1 FETCH_SIZE python $GRAFT_REPO_ROOT/scripts/pmc_target.py --size $1
+  prof 200 pmc_write_$1 WRITE_SIZE python $GRAFT_REPO_ROOT/scripts/pmc_target.py --size $1
+}
+pmc_bert()     { pmc bert; }
+pmc_resnet50() { pmc resnet50; }
+pmc_resnet18() { pmc resnet18; }
+pmc_mt()       { pmc mt_resnet50; pmc mt_bert; }
+configs()  { timeout 1500 python scripts/config_runs.py > $OUT/${TAG}_config_runs_same_process.log 2>&1; tail -12 $OUT/${TAG}_config_runs_same_process.log | cut -c1-400; }
+control()  { timeout 1500 python scripts/config_runs.py --only control > $OUT/${TAG}_same_gpu_torch_control.log 2>&1; tail -30 $OUT/${TAG}_same_gpu_torch_control.log | cut -c1-300; }
+
+set -x
+for stage in "$@"; do $stage; done

@@ -3,6 +3,7 @@ synthetic gradient list of one BASELINE size, and kernel D on the 53 BatchNorm i
 launches each, nothing else on the GPU -- the full bench under --pmc WRITE_SIZE died inside rocprofv3 twice in round 2.
 
     rocprofv3 --pmc WRITE_SIZE -- python scripts/pmc_target.py --size resnet18|resnet50|bert|bn [--reps 6]
+    ... --size mt_resnet50 | mt_bert : the multi-tensor kernels (axpy: read a, b, write out = 3 N 4 B; scale: 2 N 4 B) on that list (round 5)
     ... --size bneval_plain | bneval_tap : kernel E's backward launch over the same 53 activations without / with the DeepInversion
         term riding in it (round 4): same FETCH_SIZE / WRITE_SIZE = the prior's backward costs no traffic of its own
 """
@@ -72,6 +73,27 @@ elif args.size == "bn":
                                  _lib.ptr(coef), None, _lib.ptr(grad_flat), st), "bwd")
     torch.cuda.synchronize()
     print("bn", sum(a.numel() for a in acts), "elements", float(total))
+elif args.size.startswith("mt_"):
+    from breaching_amd.gm import ListLayout
+
+    if args.size == "mt_bert":
+        case = build_text_case(device=dev, full_size=True, seq_len=32)
+        shapes = [tuple(g.shape) for g in case.shared_data[0]["gradients"]][1:]
+        del case
+    else:
+        shapes = [tuple(q.shape) for q in ResNet(50, 1000).parameters()]
+    layout = ListLayout(shapes, dev)
+    a = [torch.randn(s, generator=gen).to(dev) for s in shapes]
+    b = [torch.randn(s, generator=gen).to(dev) for s in shapes]
+    out = layout.empty_flat()
+    st = _lib.current_stream_handle(dev)
+    for _ in range(args.reps):
+        _lib.check(lib.bh_mt_axpy(layout.n_tensors, layout.pointers(a), layout.pointers(b), None, -0.0123, _lib.ptr(layout.chunks_dev),
+                                  layout.n_chunks, layout.mt_bounds, _lib.ptr(out), st), "axpy")
+        _lib.check(lib.bh_mt_scale(layout.n_tensors, layout.pointers(a), -0.0123, _lib.ptr(layout.chunks_dev), layout.n_chunks,
+                                   layout.mt_bounds, _lib.ptr(out), st), "scale")
+    torch.cuda.synchronize()
+    print(args.size, sum(layout.numels), "elements: axpy 3 N 4 B, scale 2 N 4 B per launch")
 else:
     if args.size == "bert":
         case = build_text_case(device=dev, full_size=True, seq_len=32)

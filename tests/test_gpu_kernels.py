@@ -175,7 +175,8 @@ def test_norm_prior_matches_reference_golden(key, kw, golden_dir, hip_lib):
     _assert_grads([g.cpu().numpy()], [gold[f"norm_{key}__grad"].astype(np.float64)], rtol=1e-5)
 
 
-@pytest.mark.parametrize("shape,opp", [((1, 3, 224, 224), False), ((8, 3, 224, 224), False), ((2, 3, 33, 17), True), ((1, 3, 1, 1), False)])
+@pytest.mark.parametrize("shape,opp", [((1, 3, 224, 224), False), ((8, 3, 224, 224), False), ((2, 3, 33, 17), True), ((1, 3, 1, 1), False),
+                                       ((2, 3, 12, 16), True), ((8, 3, 224, 224), True), ((3, 3, 5, 4), False), ((1, 3, 1, 4), True)])
 def test_tv_norm_matches_c_oracle(shape, opp, kernels_oracle, hip_lib):
     from breaching_amd.priors import launch_tv_norm
     from oracle import kernels_ref
@@ -189,6 +190,30 @@ def test_tv_norm_matches_c_oracle(shape, opp, kernels_oracle, hip_lib):
     assert abs(vals[0] - tv) <= 1e-6 * abs(tv) + 1e-12
     assert abs(vals[1] - nrm) <= 1e-6 * abs(nrm) + 1e-12
     _assert_grads([grad.cpu().numpy()], [want_g], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shape,opp", [((1, 3, 224, 224), False), ((8, 3, 224, 224), False), ((8, 3, 224, 224), True), ((2, 3, 12, 16), True)])
+def test_tv_norm_16_byte_path_gradient_is_bit_identical_to_the_scalar_path(shape, opp, hip_lib):
+    """Kernel C with four pixels per thread (W % 4 == 0, aligned planes; one wavefront per workgroup for small images, 256 threads
+    for batches) against the one-pixel-per-thread kernel, which a 4-byte-offset view of the same data is routed to: the gradient
+    must agree bit for bit (same per-pixel statements), the two values to fp64 summation order."""
+    from breaching_amd.priors import launch_tv_norm
+
+    rng = np.random.default_rng(12)
+    n = int(np.prod(shape))
+    x = torch.tensor(rng.standard_normal(n).astype(np.float32), device=_dev()).view(shape)
+    holder = torch.empty(n + 4, dtype=torch.float32, device=_dev())
+    x_off = holder[1 : n + 1].view(shape)  # base address 4 bytes past a 16-byte boundary
+    x_off.copy_(x)
+    assert x.data_ptr() % 16 == 0 and x_off.data_ptr() % 16 == 4
+    g_vec, p_vec, grid_vec = launch_tv_norm(x, 0.2, 1, 1, 1e-8, opp, norm_scale=1e-3, norm_p=2.0)
+    g_off = torch.empty(n + 4, dtype=torch.float32, device=_dev())[1 : n + 1].view(shape)
+    g_sc, p_sc, grid_sc = launch_tv_norm(x_off, 0.2, 1, 1, 1e-8, opp, norm_scale=1e-3, norm_p=2.0, grad_out=g_off)
+    assert grid_vec != grid_sc or n < 100_000  # different launch geometry: the two paths really are different kernels
+    assert torch.equal(g_vec, g_sc)
+    v_vec = p_vec[: grid_vec * 2].view(grid_vec, 2).sum(dim=0)
+    v_sc = p_sc[: grid_sc * 2].view(grid_sc, 2).sum(dim=0)
+    torch.testing.assert_close(v_vec, v_sc, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
@@ -292,8 +317,9 @@ def _step_once(hip_lib, n_shape, sign_mode, boxed, decoupled, langevin, clip, st
     (2, True, False, 0.0, -1.0),   # modern: soft sign
     (0, False, False, 0.0, 0.0),   # grad_clip = 0 is a threshold, not "off": the gradient is scaled to ~0 (:171-174)
 ])
-def test_candidate_step_matches_c_oracle(sign_mode, boxed, decoupled, langevin, clip, kernels_oracle, hip_lib):
-    r = _step_once(hip_lib, (2, 3, 9, 7), sign_mode, boxed, decoupled, langevin, clip, steps=6)
+@pytest.mark.parametrize("shape", [(2, 3, 9, 7), (2, 3, 8, 12)])  # 4-byte path (n % 4 != 0) and 16-byte path
+def test_candidate_step_matches_c_oracle(shape, sign_mode, boxed, decoupled, langevin, clip, kernels_oracle, hip_lib):
+    r = _step_once(hip_lib, shape, sign_mode, boxed, decoupled, langevin, clip, steps=6)
     np.testing.assert_allclose(r["x"], r["xo"], rtol=2e-5, atol=5e-6)
     np.testing.assert_allclose(r["m"], r["mo"], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(r["v"], r["vo"], rtol=2e-5, atol=1e-7)
@@ -305,6 +331,60 @@ def test_candidate_step_matches_c_oracle(sign_mode, boxed, decoupled, langevin, 
     assert st[_lib.STATE_DEAD].item() == 1 and st[_lib.STATE_FIRST_BAD].item() == 4
     assert st[_lib.STATE_MIN : _lib.STATE_MIN + 1].view(torch.float32).item() == 1.0  # 0.5 after the NaN is ignored
     np.testing.assert_array_equal(r["history"][:4], np.float32(r["losses"][:4]))
+
+
+@pytest.mark.parametrize("sign_mode,boxed,decoupled,langevin,clip", [(1, True, False, 0.0, -1.0), (0, True, False, 0.01, -1.0), (0, False, True, 0.0, 1.0)])
+def test_candidate_step_16_byte_path_is_bit_identical_to_the_4_byte_path(sign_mode, boxed, decoupled, langevin, clip, hip_lib):
+    """Kernel B on 16-byte aligned buffers (float4 accesses, the channel box looked up once per four elements) against the same
+    launch on views that start 4 bytes past a 16-byte boundary (routed to the 4-byte kernel): x, m, v and best bit for bit, over
+    three steps, at BASELINE configs[2]'s candidate size (8 x 3 x 224 x 224)."""
+    from breaching_amd import _lib, schedules
+
+    dev = _dev()
+    B, C, H, W = 8, 3, 224, 224
+    n = B * C * H * W
+    rng = np.random.default_rng(31)
+    table = schedules.adam_schedule_table(schedules.lr_sequence(0.1, "cosine-decay", 2, 8), 0.9, 0.999, 0.01 if decoupled else 0.0)
+    sched = torch.from_numpy(table).to(dev)
+    P = _lib.StepParams()
+    P.n, P.plane, P.channels, P.boxed, P.sign_mode, P.max_iterations = n, H * W, C, int(boxed), sign_mode, 8
+    for c, (lo, hi) in enumerate(zip([-2.0, -1.9, -1.8], [2.2, 2.3, 2.4])):
+        P.lo[c], P.hi[c] = lo, hi
+    P.beta1, P.beta2, P.eps, P.decoupled_wd, P.langevin, P.grad_clip = 0.9, 0.999, 1e-8, int(decoupled), langevin, clip
+    stream = _lib.current_stream_handle(dev)
+    inputs = [dict(g=torch.tensor(rng.standard_normal(n).astype(np.float32) * (10.0 if clip >= 0 else 1.0)),
+                   greg=torch.tensor(rng.standard_normal(n).astype(np.float32) * 0.1),
+                   noise=torch.tensor(rng.standard_normal(n).astype(np.float32))) for _ in range(3)]
+    x0 = torch.tensor(rng.standard_normal(n).astype(np.float32) * 2.0)
+
+    def run(offset):
+        def buf(src=None):
+            t = torch.zeros(n + 4, dtype=torch.float32, device=dev)[offset : offset + n]
+            if src is not None:
+                t.copy_(src)
+            return t
+
+        state = torch.zeros(_lib.BH_STATE_WORDS, dtype=torch.int32, device=dev)
+        history = torch.zeros(8, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.BH_PRIOR_MAX_GRID, dtype=torch.float64, device=dev)
+        x, m, v, best = buf(x0), buf(), buf(), buf(x0)
+        assert x.data_ptr() % 16 == 4 * offset
+        _lib.check(hip_lib.bh_state_reset(_lib.ptr(state), stream), "reset")
+        for it, inp in enumerate(inputs):
+            g, greg, noise = buf(inp["g"]), buf(inp["greg"]), (buf(inp["noise"]) if langevin > 0 else None)
+            loss = torch.tensor([[3.0, 2.0, 2.5][it]], dtype=torch.float32, device=dev)
+            _lib.check(hip_lib.bh_loss_commit(_lib.ptr(state), _lib.ptr(history), 8, _lib.ptr(loss), None, 0, None, None, stream), "commit")
+            if clip >= 0:
+                _lib.check(hip_lib.bh_grad_norm(_lib.ptr(state), _lib.ptr(g), _lib.ptr(greg), _lib.ptr(noise), n, _lib.ptr(sched), langevin, _lib.ptr(ws), stream), "norm")
+            _lib.check(hip_lib.bh_candidate_step(_lib.ptr(state), _lib.ptr(sched), P, _lib.ptr(x), _lib.ptr(g), _lib.ptr(greg), _lib.ptr(noise),
+                                                 _lib.ptr(m), _lib.ptr(v), _lib.ptr(best), stream), "step")
+        torch.cuda.synchronize()
+        return x.clone(), m.clone(), v.clone(), best.clone()
+
+    vec, scalar = run(0), run(1)
+    for a, b, name in zip(vec, scalar, ("x", "m", "v", "best")):
+        assert torch.equal(a, b), name
+    assert not torch.equal(vec[0], vec[3])  # the third loss (2.5) did not improve: best kept the second iterate
 
 
 def test_candidate_step_best_copy_is_post_step_candidate(kernels_oracle, hip_lib):
