@@ -20,6 +20,14 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     `roofline.hbm_resident`: the same kernels timed in the same run on a synthetic list of BERT-base's 201 gradient tensors
     (86.07 M elements, 688.6 MB per forward launch -- 2.7x the 256 MiB Infinity Cache, so this is an HBM figure, which the
     ResNet-18 list's is not).
+    `roofline.ceiling`: what a launch shaped like kernel A's forward (same persistent grid, same eight staged 16-byte loads
+    per lane, two multiply-adds per element instead of the objective; scripts/diag/read_ceiling.hip, NOT part of the library)
+    reaches on buffers of the same size in this run, right behind a writer -- for a list that streams from the 256 MiB
+    Infinity Cache (ResNet-18's does) the 8 TB/s HBM peak is the wrong denominator, this is the measured one.
+  * parity: one teacher-forced evaluation of the timed configuration at the reference's own late iterate (k = 23 991 of the
+    24 000-iteration CPU run of the unmodified reference, tests/golden/attack_resnet18_24k.npz) -- loss and step direction.
+  * gpu_torch_baseline: the same attack with PyTorch-ROCm ops for the attack-side arithmetic (oracle/restate.py on the GPU, no
+    kernel of libbreach_hip.so), a bounded number of iterations: what the HIP path buys ON THIS CHIP.  A reported baseline.
   * cpu_baseline: the UNMODIFIED reference through oracle/ref_shim.py when a reference checkout is importable
     (`kind: "reference"`; /root/reference in the build container, BREACHING_REFERENCE elsewhere), else oracle/restate.py (CPU
     restatement pinned to the reference by tests/test_oracle_pinning.py; `kind: "port"`, with the committed port / reference
@@ -106,6 +114,7 @@ def hbm_resident_leg(device, reps=30):
         torch.cuda.synchronize(device)
         t = plan.drain_timers()
         f, e, b = (sum(sorted(t[k])[:-5]) / (len(t[k]) - 5) for k in ("fwd", "fin", "bwd"))
+        spread = {k: dict(min=round(min(t[k]), 2), median=round(sorted(t[k])[len(t[k]) // 2], 2), max=round(max(t[k]), 2)) for k in ("fwd", "bwd")}
         # the same forward launch with nothing but its own finalize between repetitions: in the triple above every forward
         # follows a backward that has just written 344 MB, whose write-back competes with the forward's reads (the in-loop
         # condition: there autograd has just written the reconstructed list)
@@ -119,9 +128,135 @@ def hbm_resident_leg(device, reps=30):
                               fwd_GBs=round(2 * n * 4 / f / 1e3, 1), frac=round(2 * n * 4 / f / 1e3 / HBM_PEAK_GBS, 4),
                               stage_frac=round(2 * n * 4 / (f + e) / 1e3 / HBM_PEAK_GBS, 4),
                               bwd_GBs=round(3 * n * 4 / b / 1e3, 1), bwd_frac=round(3 * n * 4 / b / 1e3 / HBM_PEAK_GBS, 4),
-                              fwd_not_behind_a_writer_us=round(fa, 2), frac_not_behind_a_writer=round(2 * n * 4 / fa / 1e3 / HBM_PEAK_GBS, 4))
+                              fwd_not_behind_a_writer_us=round(fa, 2), frac_not_behind_a_writer=round(2 * n * 4 / fa / 1e3 / HBM_PEAK_GBS, 4),
+                              fwd_us_min_median_max=spread["fwd"], bwd_us_min_median_max=spread["bwd"],
+                              frac_at_min_us=round(2 * n * 4 / spread["fwd"]["min"] / 1e3 / HBM_PEAK_GBS, 4),
+                              frac_at_median_us=round(2 * n * 4 / spread["fwd"]["median"] / 1e3 / HBM_PEAK_GBS, 4))
     plan.timers = None
     return out
+
+
+def read_ceiling_leg(device, n_elements, kernel_us, reps=30):
+    """The measured ceiling of a launch shaped like kernel A's forward at this list size: scripts/diag/read_ceiling.hip (a
+    diagnostic kernel OUTSIDE libbreach_hip.so: kernel A's persistent grid of 512 workgroups and eight staged 16-byte loads per
+    lane over two buffers, two multiply-adds per element), each launch right behind a kernel that has just rewritten the first
+    buffer (what autograd does to the reconstructed gradient list), timed with the dispatch's own start / stop events."""
+    import ctypes
+    import subprocess
+
+    import torch
+
+    from breaching_amd import _lib
+
+    src = os.path.join(ROOT, "scripts", "diag", "read_ceiling.hip")
+    lib_path = os.path.join(ROOT, "scripts", "diag", "libread_ceiling.so")
+    if not os.path.exists(lib_path) and os.path.exists(src):  # built in-tree by __graft_entry__.build(); last resort here
+        subprocess.run([os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
+                        src, "-o", lib_path], check=True, capture_output=True)
+    diag = ctypes.CDLL(lib_path)
+    diag.diag_read_timed.restype = ctypes.c_int
+    diag.diag_read_timed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                     ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_float)]
+    n_chunks = n_elements // 4096
+    a, b = torch.randn(n_chunks * 4096, device=device), torch.randn(n_chunks * 4096, device=device)
+    sink = torch.zeros(4096, device=device)
+    nbytes = 2 * n_chunks * 4096 * 4
+    stream = _lib.current_stream_handle(device)
+    out = dict(kind="read probe with kernel A's grid and loads (scripts/diag/read_ceiling.hip, outside the library), each launch behind a "
+                    "writer of the first buffer; dispatch start/stop events", bytes=nbytes)
+    for tag, fill in (("behind_writer", 1), ("warm", 0)):
+        us = (ctypes.c_float * (reps + 5))()
+        rc = diag.diag_read_timed(a.data_ptr(), b.data_ptr(), n_chunks, 512, 0, sink.data_ptr(), stream, fill, reps + 5, us)
+        if rc != 0:
+            return dict(error=f"diag_read_timed returned {rc}")
+        t = sorted(us[5:])
+        out[tag] = dict(min_us=round(t[0], 2), median_us=round(t[len(t) // 2], 2), max_us=round(t[-1], 2),
+                        GBs=round(nbytes / t[len(t) // 2] / 1e3, 1), frac_of_hbm_peak=round(nbytes / t[len(t) // 2] / 1e3 / HBM_PEAK_GBS, 4))
+    out["us"], out["GBs"] = out["behind_writer"]["median_us"], out["behind_writer"]["GBs"]
+    out["kernel_A_forward_over_ceiling"] = round(out["us"] / kernel_us, 4)  # 1.0 = kernel A's forward takes what the bare read takes
+    return out
+
+
+def parity_leg(device, model_name):
+    """The timed configuration against the unmodified reference, in one evaluation: at the reference's own iterate x_k of its
+    24 000-iteration CPU run (the latest stored one, k = 23 991; tests/golden/attack_resnet18_24k.npz, written by
+    oracle/make_golden.py golden_resnet18_24k) the HIP path's objective (kernel A forward behind the victim's double backward +
+    kernel C) against the reference's history[k], and sign(d total / dx) -- what hard-sign Adam consumes -- against the
+    reference's sign map, next to the reference's OWN agreement with itself when x_k moves by <= 16 ulp."""
+    import numpy as np
+    import torch
+
+    import breaching_amd
+    from breaching_amd.cases import build_case, parameter_checksum
+
+    path = os.path.join(ROOT, "tests", "golden", "attack_resnet18_24k.npz")
+    if model_name != "resnet18" or not os.path.exists(path):
+        return None
+    gold = np.load(path)
+    case = build_case("resnet18", "ImageNet", 1, device=device)  # observed gradient computed on the CPU: the target the reference attacked
+    if abs(parameter_checksum(case.model) / float(gold["model_checksum"]) - 1) > 1e-10:
+        return dict(error="model of this run differs from the fixture's")
+    cfg = breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={int(gold['iterations'])}"])
+    attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, dict(device=device, dtype=torch.float))
+    shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+    rec_models, labels, _ = attacker.prepare_attack(case.server_payload, shared)
+    for reg in attacker.regularizers:
+        reg.initialize(rec_models, shared, labels)
+    attacker.objective.initialize(attacker.loss_fn, cfg.impl, None)
+    attacker.objective.prepare(rec_models, shared)
+    i = int(np.argmax(gold["forced_k"]))
+    k = int(gold["forced_k"][i])
+    xk = torch.as_tensor(gold["forced_x"][i]).to(device).clone().requires_grad_(True)
+    total, _ = attacker._autograd_objective([xk], labels, rec_models, shared, attacker.regularizers)
+    (g,) = torch.autograd.grad(total, [xk])
+    g = g.detach().cpu()
+    sign_ref = torch.as_tensor(gold["forced_sign"][i].astype(np.float32))
+    weight = torch.as_tensor((gold["forced_grad_bf16"][i].astype(np.uint32) << 16).view(np.float32)).abs().double()
+    same = (torch.sign(g) == sign_ref).double()
+    want = float(gold["history"][k])
+    ref_psnr = np.concatenate([[gold["psnr"]], gold["twin_psnr"]])
+    out = dict(fixture="tests/golden/attack_resnet18_24k.npz (unmodified reference on CPU, 24 000 iterations)", iterate=k,
+               loss_reference=want, loss_hip=float(total), loss_rel_err=abs(float(total) - want) / want,
+               loss_tolerance=max(1e-4, 10.0 * float(gold["forced_sensitivity"][i])),
+               sign_agreement=float(same.mean()), reference_twin_agreement=float(gold["forced_twin_sign_agreement"][i]),
+               weighted_sign_agreement=float((same * weight).sum() / weight.sum()),
+               reference_twin_weighted_agreement=float(gold["forced_twin_weighted_sign_agreement"][i]),
+               psnr_db_reference_runs=dict(mean=round(float(ref_psnr.mean()), 4), n=int(len(ref_psnr))))
+    out["ok"] = bool(out["loss_rel_err"] <= out["loss_tolerance"] and
+                     1 - out["sign_agreement"] <= 3 * (1 - out["reference_twin_agreement"]) + 1e-3)
+    hip_runs = os.path.join(ROOT, "profiles", "r5_config1_24k_8starts.json")  # free-running HIP runs of the full horizon (committed)
+    if os.path.exists(hip_runs):
+        try:
+            with open(hip_runs) as f:
+                rec = json.load(f)
+            out["psnr_db_hip_runs"] = dict(mean=round(float(np.mean(rec["hip"]["psnr_db"])), 4), n=len(rec["hip"]["psnr_db"]), file="profiles/r5_config1_24k_8starts.json")
+        except Exception:
+            pass
+    return out
+
+
+def gpu_torch_baseline_leg(device, model_name, iters):
+    """The same attack on the same GPU with PyTorch-ROCm ops for everything: oracle/restate.py (the statement-by-statement
+    restatement of the reference loop) with device = cuda.  Same victim model arithmetic as the HIP path; about 1.5 k ATen launches
+    per iteration for the attack-side arithmetic instead of kernels A / B / C.  Eager, one process, `iters` iterations after 3."""
+    import torch
+
+    import breaching_amd
+    from breaching_amd.cases import build_case, initial_candidate
+    from oracle import restate
+
+    case = build_case(model_name, "ImageNet", 1, device=device, gradient_device=device)
+    cfg = breaching_amd.get_attack_config("invertinggradients")
+    x0 = initial_candidate(case.data_cfg, 1)
+    restate.run_attack(case.model, case.loss_fn, cfg, case.server_payload, case.shared_data, initial_data=x0, max_iterations=3, device=device)
+    torch.cuda.synchronize(device)
+    timing = []
+    _, stats = restate.run_attack(case.model, case.loss_fn, cfg, case.server_payload, case.shared_data, initial_data=x0, max_iterations=iters,
+                                  device=device, timing=timing)
+    return dict(value=round(iters / timing[0], 3), unit="attack iterations/s", kind="port on the GPU (oracle/restate.py, PyTorch-ROCm ops, eager)",
+                sample=f"{iters} iterations of the same {model_name}/224 invertinggradients workload after 3 warm-up iterations; the loop "
+                       "synchronises once per iteration (`.item()` of the loss), as the reference's does",
+                final_objective=stats["Trial_0_Val"][-1])
 
 
 def cpu_anchor_ratio():
@@ -207,6 +342,9 @@ def parse_args():
                    help="threads of the CPU baseline (0 = min(os.cpu_count(), 16): the measured optimum, profiles/r4_cpu_thread_sweep.json)")
     p.add_argument("--gm-cache-policy", default=None, metavar="FWD[,BWD]",
                    help="force kernel A's cache policy (0 auto / 1 plain / 2 non-temporal loads / 3 + non-temporal stores), forward[,backward]")
+    p.add_argument("--gpu-torch-baseline-iters", type=int, default=60,
+                   help="timed iterations of the PyTorch-ROCm port of the attack on the same GPU (0 disables); N = 1 only")
+    p.add_argument("--no-parity", action="store_true", help="skip the teacher-forced parity evaluation against the reference fixture")
     p.add_argument("--no-hbm-resident", action="store_true", help="skip the BERT-base sized kernel-A timing (roofline.hbm_resident)")
     p.add_argument("--model", default="resnet18")
     p.add_argument("--no-kernel-timing", action="store_true")
@@ -447,6 +585,14 @@ def main():
                 roofline["hbm_resident"] = hbm_resident_leg(device)
         except Exception as exc:  # e.g. out of memory next to another tenant: reported, never fatal for the headline value
             roofline["hbm_resident"] = dict(error=repr(exc))
+    if roofline is not None and "fwd" in kernels and rank == 0 and world == 1 and not args.no_kernel_timing:
+        try:
+            with torch.cuda.stream(first_stream):
+                roofline["ceiling"] = read_ceiling_leg(device, n_elements, kernels["fwd"]["avg_us"])
+            if "us" in roofline["ceiling"]:
+                roofline["frac_of_ceiling"] = round(roofline["ceiling"]["us"] / kernels["fwd"]["avg_us"], 4)
+        except Exception as exc:  # the diagnostic library is not part of the product: its absence never fails the bench
+            roofline["ceiling"] = dict(error=repr(exc)[:300])
     if "bwd" in kernels:
         kernels["bwd"]["traffic"] = pmc_traffic_bytes("gm_bwd_kernel")
         kernels["bwd"]["frac_of_hbm_peak"] = round(kernels["bwd"]["achieved_GBs"] / HBM_PEAK_GBS, 4)
@@ -481,6 +627,19 @@ def main():
         except Exception as exc:  # a timeout included: reported, never fatal for the measurement
             rccl_dry_run = dict(ok=False, error=repr(exc))
 
+    # ---- parity of the timed configuration + the same-GPU PyTorch baseline (rank 0, N == 1 only; after the timed region) -----
+    parity = gpu_torch_baseline = None
+    if rank == 0 and world == 1 and not args.no_parity:
+        try:
+            parity = parity_leg(device, args.model)
+        except Exception as exc:
+            parity = dict(error=repr(exc)[:300])
+    if rank == 0 and world == 1 and args.gpu_torch_baseline_iters > 0:
+        try:
+            gpu_torch_baseline = gpu_torch_baseline_leg(device, args.model, args.gpu_torch_baseline_iters)
+        except Exception as exc:
+            gpu_torch_baseline = dict(error=repr(exc)[:300])
+
     # ---- CPU baseline (rank 0, N == 1 only) ---------------------------------------------------------------------------
     cpu_baseline = None
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
@@ -488,7 +647,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "attack iters/sec, ResNet-18 ImageNet invertinggradients",
+            "metric": "attack iters/sec, ResNet-18 ImageNet invertinggradients; PSNR vs ref",
             "value": round(world * args.trials_per_gpu * args.steps / elapsed, 3),
             "unit": "attack iterations/s",
             "n_gpus": world,
@@ -508,6 +667,8 @@ def main():
                        "trials_in_flight_per_gpu": args.trials_per_gpu, "parallelism": f"trial-parallel x{world}"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "gpu_torch_baseline": gpu_torch_baseline,
+            "parity": parity,
             "kernels": kernels,
             "launch_mode": mode,
             "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 4),

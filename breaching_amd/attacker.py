@@ -194,6 +194,7 @@ class HipOptimizationAttacker:
         # How this call was executed, on the channel callers already read (base_attack.py:45): per-trial launch mode of
         # this rank's trials, the pool that shared the trials (backend, world, devices) or why there was none.
         stats["execution"] = dict(trials=stats.pop("execution_trials"), pool=pool.describe() if pool is not None else None,
+                                  fused_epilogue_fallback=getattr(self, "fused_epilogue_fallback", None),
                                   pool_fallback=getattr(self, "_pool_fallback", None), world=shard.world,
                                   trial_streams=trial_streams.calibration_report(self.setup["device"]))
         reconstructed_data = self._package(optimal, labels)
@@ -698,7 +699,21 @@ class HipOptimizationAttacker:
         total_task_loss = 0
         obj_labels = self._labels_for_objective(candidates, labels)
         for model, data in zip(rec_model, shared_data):
-            objective, task_loss = self.objective(model, data["gradients"], candidate, obj_labels)
+            try:
+                objective, task_loss = self.objective(model, data["gradients"], candidate, obj_labels)
+            except FusedEpilogueError as exc:
+                # fuse_bn_relu="auto": this model's forward cannot take the deferred BatchNorm launch.  Nothing of the iteration
+                # has been committed yet (the error is raised inside the victim's forward pass): switch the fusion off on this
+                # model copy and evaluate again -- more launches, same values.  Not possible while a hipGraph is being captured.
+                if fuse_bn_relu_policy(self.cfg) == "required" or torch.cuda.is_current_stream_capturing():
+                    raise
+                switched = sum(1 for m in model.modules() if isinstance(m, _EvalAffineBatchNorm2d) and m.fuse_epilogue)
+                for m in model.modules():
+                    if isinstance(m, _EvalAffineBatchNorm2d):
+                        m.fuse_epilogue = False
+                self.fused_epilogue_fallback = f"BatchNorm -> ReLU fusion switched off on {switched} layers: {exc}"
+                log.warning(f"{self.fused_epilogue_fallback}  (cfg.impl.fuse_bn_relu='required' turns this into an error.)")
+                objective, task_loss = self.objective(model, data["gradients"], candidate, obj_labels)
             total_objective = total_objective + objective
             total_task_loss = total_task_loss + task_loss
         for regularizer in autograd_regularizers:
@@ -1038,6 +1053,12 @@ _ADD_OUT_OF_PLACE = (torch.add, torch.Tensor.add, torch.Tensor.__add__, torch.Te
 _ADD_IN_PLACE = (torch.Tensor.add_, torch.Tensor.__iadd__)
 
 
+class FusedEpilogueError(RuntimeError):
+    """The deferred BatchNorm launch (`_PendingBatchNorm`) met a consumer it cannot serve.  With cfg.impl.fuse_bn_relu = "auto" (the
+    default) the attacker catches it on the model copy it happened on, switches the epilogue fusion off there and repeats the
+    evaluation; "required" lets it through."""
+
+
 class _PendingBatchNorm(torch.Tensor):
     """The not-yet-launched output of an eval-mode BatchNorm on kernel E: a metadata-only tensor that waits for its first
     consumer.  `+ identity` / `+= identity` is absorbed as the launch's residual, `relu` / `relu_` launches
@@ -1065,9 +1086,10 @@ class _PendingBatchNorm(torch.Tensor):
             # Created where autograd was recording, consumed where it is not: the consumer is almost certainly the forward of a
             # custom autograd.Function, which received this metadata-only wrapper as an input and therefore has no autograd
             # edge to the BatchNorm input -- its gradient would silently stop here.  Fail loudly instead.
-            raise RuntimeError("An eval-mode BatchNorm output was handed to a custom autograd.Function (or consumed inside a "
-                               "no_grad block) before any ordinary operation used it; the deferred BatchNorm launch cannot carry "
-                               "an autograd edge there.  Set cfg.impl.fuse_bn_relu=False (or BREACH_HIP_FUSE_BN_RELU=0).")
+            raise FusedEpilogueError("An eval-mode BatchNorm output was handed to a custom autograd.Function (or consumed inside a "
+                                     "no_grad block) before any ordinary operation used it; the deferred BatchNorm launch cannot "
+                                     "carry an autograd edge there.  cfg.impl.fuse_bn_relu='auto' (the default) falls back to "
+                                     "un-fused launches on this model; False (or BREACH_HIP_FUSE_BN_RELU=0) never defers.")
         return _launch_eval_bn(self._module, self._x, self._sink, self._tap, self._residual, relu)
 
     def value(self):
@@ -1084,7 +1106,9 @@ class _PendingBatchNorm(torch.Tensor):
         first = args[0] if args else None
         fresh = isinstance(first, cls) and first._value is None
         if fresh and len(args) == 1 and func in _RELU_OUT_OF_PLACE and not kwargs.get("inplace", False):
-            return first.launch(relu=True)  # `first` itself stays pending: a second consumer still gets the un-clamped values
+            out = first.launch(relu=True)  # `first` itself stays pending: a second consumer still gets the un-clamped values --
+            first._sink = first._tap = None  # -- but the statistics sink and the DeepInversion tap belong to this first launch only
+            return out
         if fresh and len(args) == 1 and (func in _RELU_IN_PLACE or (func is torch.nn.functional.relu and kwargs.get("inplace", False))):
             first._value = first.launch(relu=True)
             return first._value
@@ -1094,8 +1118,8 @@ class _PendingBatchNorm(torch.Tensor):
                 a, b = args
                 if func in _ADD_OUT_OF_PLACE and not (isinstance(a, cls) and a._value is None and a._residual is None):
                     a, b = b, a  # identity + bn(...)
-                if (isinstance(a, cls) and a._value is None and a._residual is None and b.shape == a.shape and b.dtype == a.dtype
-                        and b.device == a.device):
+                if (isinstance(a, cls) and a._value is None and a._residual is None and b is not a and b.shape == a.shape
+                        and b.dtype == a.dtype and b.device == a.device):
                     other = b.value() if isinstance(b, cls) else b
                     if func in _ADD_IN_PLACE:
                         if a is args[0]:
@@ -1104,6 +1128,7 @@ class _PendingBatchNorm(torch.Tensor):
                     else:
                         merged = cls(a._module, a._x, a._sink, a._tap)
                         merged._residual = other
+                        a._sink = a._tap = None  # handed on to `merged`: a later use of `a` itself launches without them
                         return merged
         name = getattr(func, "__name__", "")
         if name == "__get__" and args and isinstance(first, cls) and getattr(getattr(func, "__self__", None), "__name__", "") in (
@@ -1136,15 +1161,29 @@ class _PendingBatchNorm(torch.Tensor):
         return f"_PendingBatchNorm(shape={tuple(self.shape)}, residual={self._residual is not None}, launched={self._value is not None})"
 
 
-def fuse_bn_relu_enabled(cfg=None):
-    """BatchNorm -> (+ residual) -> ReLU in kernel E's launches: on unless BREACH_HIP_FUSE_BN_RELU=0 or cfg.impl.fuse_bn_relu is false."""
+def fuse_bn_relu_policy(cfg=None):
+    """BatchNorm -> (+ residual) -> ReLU in kernel E's launches: "auto" (default: on; a victim model whose forward hands a BatchNorm
+    output straight to a custom autograd.Function or a no_grad consumer -- the one thing the deferred launch cannot serve -- gets
+    the fusion switched off on its copy at the first evaluation, with a warning and a note in stats["execution"]), "required" (that
+    case raises) or "off".  cfg.impl.fuse_bn_relu = True / "auto" / "required" / False, or BREACH_HIP_FUSE_BN_RELU = 1 / auto /
+    required / 0.  The reference attacks arbitrary models (objectives.py:36-46): the default must never be the reason one cannot be."""
     import os
 
-    env = os.environ.get("BREACH_HIP_FUSE_BN_RELU")
-    if env is not None:
-        return env.strip().lower() not in ("0", "false", "off", "no")
-    flag = _cfg_get(cfg.impl, "fuse_bn_relu", True) if cfg is not None else True
-    return True if flag is None else bool(flag)
+    flag = os.environ.get("BREACH_HIP_FUSE_BN_RELU")
+    if flag is None:
+        flag = _cfg_get(cfg.impl, "fuse_bn_relu", True) if cfg is not None else True
+    if flag is None:
+        return "auto"
+    if isinstance(flag, str):
+        flag = flag.strip().lower()
+        if flag in ("required", "require", "strict"):
+            return "required"
+        return "off" if flag in ("0", "false", "off", "no") else "auto"
+    return "auto" if bool(flag) else "off"
+
+
+def fuse_bn_relu_enabled(cfg=None):
+    return fuse_bn_relu_policy(cfg) != "off"
 
 
 class _EvalAffineBatchNorm2d(torch.nn.BatchNorm2d):

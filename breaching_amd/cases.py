@@ -376,9 +376,10 @@ def multi_step_update(model, loss_fn, x, labels, steps, data_per_step, lr):
                                local_hyperparams=dict(lr=lr, steps=steps, data_per_step=data_per_step, labels=step_labels)))]
 
 
-def build_fedavg_case(device="cpu", num_data_points=4, steps=2, data_per_step=2, lr=0.05, seed_model=0, seed_data=1):
-    data_cfg = get_data_config("CIFAR10")
-    model = build_model("convnet", data_cfg.classes, seed_model)
+def build_fedavg_case(device="cpu", num_data_points=4, steps=2, data_per_step=2, lr=0.05, seed_model=0, seed_data=1,
+                      model_name="convnet", data_name="CIFAR10"):
+    data_cfg = get_data_config(data_name)
+    model = build_model(model_name, data_cfg.classes, seed_model)
     loss_fn = torch.nn.CrossEntropyLoss()
     x_true, labels = synthetic_user_data(data_cfg, num_data_points, seed_data)
     shared = multi_step_update(model, loss_fn, x_true, labels, steps, data_per_step, lr)

@@ -117,7 +117,24 @@ def side_streams(device, n):
         return [torch.cuda.Stream(device) for _ in range(n)]
     entry = _CHOSEN.get(index)
     if entry is None or len(entry[0]) < n:
-        entry = _CHOSEN[index] = calibrate(torch.device("cuda", index), PIPES)
+        # The probe captures and replays two small hipGraphs.  Where that cannot work (capture unsupported, a profiler that refuses
+        # it) or its timing cannot be trusted (another tenant on the GPU, ranks sharing one device and calibrating at the same time:
+        # `incomplete`), the attack must still run: fall back to plain pool streams -- round 3's behaviour, at worst slower --
+        # and say so (calibration_report() -> stats["execution"]).
+        try:
+            streams, report = calibrate(torch.device("cuda", index), PIPES)
+        except Exception as exc:  # noqa: BLE001 -- any failure of the measurement is a reason to fall back, never to abort the attack
+            streams, report = None, dict(method="fallback: next streams of torch's pool", failed=repr(exc)[:300])
+            log.warning(f"Trial-stream calibration on cuda:{index} failed ({exc!r}); using plain pool streams.")
+        if streams is not None and report.get("incomplete"):
+            log.warning(f"Trial-stream calibration on cuda:{index} found fewer than {PIPES} collision-free streams ({report}); "
+                        "using plain pool streams.")
+            report = dict(report, method="fallback: next streams of torch's pool (calibration incomplete)")
+            streams = None
+        if streams is None:
+            with torch.cuda.device(index):
+                streams = [torch.cuda.Stream(torch.device("cuda", index)) for _ in range(PIPES)]
+        entry = _CHOSEN[index] = (streams, report)
     return list(entry[0][:n])
 
 

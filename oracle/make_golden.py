@@ -1009,6 +1009,84 @@ def golden_tag_bert_base_1000():
     assemble_tag_bert_base_1000()
 
 
+# ---- BASELINE configs[2] on its real schedule: warm-up 50 + cosine decay, Langevin noise, 300 iterations --------------------
+SEE_LONG_ITERS = 300
+SEE_LONG_RUNS = {0: dict(seed=11, ulps=0), 1: dict(seed=11, ulps=16), 2: dict(seed=12, ulps=0)}  # nominal, same-noise twin, other noise
+
+
+def _seethrough_b8_long_worker(idx, out_path, threads=1, iters=SEE_LONG_ITERS):
+    """One run of the unmodified reference on ResNet-50, 8 images, seethroughgradients.yaml as shipped except for the horizon
+    (max_iterations 300 instead of 20 000: the cosine period follows it, warm-up stays 50, seethroughgradients.yaml:20-23):
+    euclidean 1e-4 + TV + L2 norm + DeepInversion 0.1, Langevin noise 0.01 from torch's seeded CPU generator
+    (optimization_based_attack.py:167-170), labels recovered with `yin`, user BN buffers.  idx 0 nominal; idx 1 the same noise
+    stream from a start <= 16 ulp away (the reference's own reproducibility envelope); idx 2 another noise stream (what "not the
+    same run" looks like).  The history so far is rewritten to `<out>.partial.npy` every 10 iterations."""
+    import time as _time
+
+    from breaching_amd.cases import build_case, initial_candidate, parameter_checksum, psnr
+
+    torch.set_num_threads(threads)
+    spec = SEE_LONG_RUNS[idx]
+    case = build_case("resnet50", "ImageNet", 8, provide_buffers=True, provide_labels=False)
+    x0 = initial_candidate(case.data_cfg, 8)
+    if spec["ulps"]:
+        x0 = _ulp_perturb(x0, spec["ulps"], torch.Generator().manual_seed(LONG_SEED))
+    cfg = _cfg("seethroughgradients", [f"optim.max_iterations={iters}", "optim.callback=50"])
+    assert cfg.optim.langevin_noise == 0.01 and cfg.label_strategy == "yin" and cfg.optim.warmup == 50
+    assert cfg.optim.step_size_decay == "cosine-decay" and cfg.optim.signed is False
+    breaching = import_reference()
+    attacker = breaching.attacks.prepare_attack(case.model, case.loss_fn, cfg, dict(device=torch.device("cpu"), dtype=torch.float))
+    inner_trial = attacker._run_trial
+    seen = {}
+
+    def spy_trial(rec_model, shared_data, labels, stats, trial, initial_data=None, dryrun=False):
+        seen["stats"] = stats
+        return inner_trial(rec_model, shared_data, labels, stats, trial, initial_data, dryrun)
+
+    attacker._run_trial = spy_trial
+    inner_compute = attacker._compute_objective
+    t0 = _time.time()
+
+    def timed_compute(candidate, labels, rec_model, optimizer, shared_data, iteration):
+        if iteration % 10 == 0 and iteration > 0:
+            print(f"  see-through run {idx}: iteration {iteration}, {(_time.time() - t0) / iteration:.2f} s/it, "
+                  f"loss {seen['stats']['Trial_0_Val'][-1]:.6f}", flush=True)
+            np.save(out_path + ".partial.npy", np.asarray(seen["stats"]["Trial_0_Val"], dtype=np.float32))
+        return inner_compute(candidate, labels, rec_model, optimizer, shared_data, iteration)
+
+    attacker._compute_objective = timed_compute
+    torch.manual_seed(spec["seed"])
+    shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+    rec, stats = attacker.reconstruct(case.server_payload, shared, {}, initial_data=x0)
+    data = rec["data"].detach()
+    out = dict(history=np.asarray(stats["Trial_0_Val"], dtype=np.float32), opt_value=np.float64(stats["opt_value"]),
+               psnr=np.float64(psnr(data, case.true_user_data["data"], case.data_cfg)), labels=rec["labels"].numpy(),
+               rec_mean=np.float64(data.double().mean()), rec_std=np.float64(data.double().std()), rec=data[..., :32, :32].numpy(),
+               seed=np.int64(spec["seed"]), ulps=np.int64(spec["ulps"]), seconds=np.float64(_time.time() - t0), threads=np.int64(threads))
+    if idx == 0:
+        out.update(model_checksum=np.float64(parameter_checksum(case.model)), true_labels=case.true_user_data["labels"].numpy(),
+                   grad0_checksum=np.float64(case.shared_data[0]["gradients"][0].double().sum()))
+    np.savez(out_path, **out)
+
+
+def assemble_seethrough_b8_long():
+    main = dict(np.load(os.path.join(TAG_LONG_DIR, "see0.npz")))
+    twin, other = np.load(os.path.join(TAG_LONG_DIR, "see1.npz")), np.load(os.path.join(TAG_LONG_DIR, "see2.npz"))
+    for tag, run in (("twin", twin), ("other_noise", other)):
+        main.update({f"{tag}_{k}": run[k] for k in ("history", "opt_value", "psnr", "rec", "rec_mean", "rec_std", "seed", "ulps")})
+    main.update(iterations=np.int64(len(main["history"])), twin_start_seed=np.int64(LONG_SEED))
+    np.savez_compressed(os.path.join(GOLDEN, "attack_seethrough_b8_long.npz"), **main)
+
+
+def golden_seethrough_b8_long():
+    os.makedirs(TAG_LONG_DIR, exist_ok=True)
+    for idx in SEE_LONG_RUNS:
+        path = os.path.join(TAG_LONG_DIR, f"see{idx}.npz")
+        if not os.path.exists(path):
+            _seethrough_b8_long_worker(idx, path, threads=int(os.environ.get("GOLDEN_THREADS", "8")))
+    assemble_seethrough_b8_long()
+
+
 class _LegacyTorchSemantics:
     """Harness-side shim (no reference file is touched) that lets the reference's Pearlmutter objectives run under torch 2.x:
     they were written for torch 1.10, where (a) `torch._foreach_add_/_foreach_sub_` on parameters that require grad did not
@@ -1121,9 +1199,10 @@ STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_sc
              variants=golden_variants, fedavg=golden_fedavg, labels=golden_labels, dlg=golden_dlg, multiquery=golden_multiquery,
              resnet18_long=golden_resnet18_long, seethrough_b8=golden_seethrough_b8, tag_bert_base=golden_tag_bert_base,
              pearlmutter=golden_pearlmutter, resnet18_24k=golden_resnet18_24k, seethrough_noise=golden_seethrough_noise,
-             resnet18_long_signs=golden_resnet18_long_signs, tag_bert_base_1000=golden_tag_bert_base_1000)
+             resnet18_long_signs=golden_resnet18_long_signs, tag_bert_base_1000=golden_tag_bert_base_1000,
+             seethrough_b8_long=golden_seethrough_b8_long)
 SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base", "resnet18_24k", "seethrough_noise", "resnet18_long_signs",
-              "tag_bert_base_1000")  # hours of CPU: only run when asked for by name
+              "tag_bert_base_1000", "seethrough_b8_long")  # hours of CPU: only run when asked for by name
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
@@ -1131,6 +1210,7 @@ if __name__ == "__main__":
     parser.add_argument("--long-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
     parser.add_argument("--full-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
     parser.add_argument("--full-iters", type=int, default=None, help="(testing the generator) shorter horizon")
+    parser.add_argument("--seethrough-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
     parser.add_argument("--tag-worker", nargs=2, default=None, metavar=("IDX", "OUT"))
     parser.add_argument("--threads", type=int, default=2, help="torch CPU threads of a --long-worker / --full-worker run")
     args = parser.parse_args()
@@ -1138,6 +1218,10 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if args.long_worker is not None:
         _resnet18_long_worker(int(args.long_worker[0]), args.long_worker[1])
+        sys.exit(0)
+    if args.seethrough_worker is not None:
+        _seethrough_b8_long_worker(int(args.seethrough_worker[0]), args.seethrough_worker[1], threads=args.threads,
+                                   iters=args.full_iters or SEE_LONG_ITERS)
         sys.exit(0)
     if args.tag_worker is not None:
         _tag_bert_base_1000_worker(int(args.tag_worker[0]), args.tag_worker[1], threads=args.threads, iters=args.full_iters)

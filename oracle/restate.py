@@ -330,35 +330,40 @@ def make_optimizer(params, name, step_size, scheduler=None, warmup=0, max_iterat
 # the attack loop  (breaching/attacks/optimization_based_attack.py, base_attack.py)
 # ---------------------------------------------------------------------------------------------------------------
 def run_attack(model, loss_fn, cfg, server_payload, shared_data, initial_data=None, dryrun=False, max_iterations=None,
-               timing=None):
+               timing=None, device="cpu"):
     """Restatement of ``OptimizationBasedAttacker.reconstruct`` for honest-server vision cases with labels provided
-    (optimization_based_attack.py:63-218; base_attack.py:43-74, :169-212).  Returns (dict(data, labels), stats)."""
+    (optimization_based_attack.py:63-218; base_attack.py:43-74, :169-212).  Returns (dict(data, labels), stats).
+
+    ``device``: "cpu" is the oracle.  "cuda:0" runs the SAME statements with PyTorch-ROCm ops -- the same-GPU control of the
+    HIP path (same victim-model arithmetic, torch's own elementwise / reduction kernels for the attack side); used by
+    tests/control_same_gpu_torch.py and bench.py's `gpu_torch_baseline` leg, never by the product."""
+    device = torch.device(device)
     import copy
 
     stats = defaultdict(list)
     meta = server_payload[0]["metadata"]
     shape = list(meta.shape)
-    dm = torch.as_tensor(meta.mean, dtype=torch.float32)[None, :, None, None]
-    ds = torch.as_tensor(meta.std, dtype=torch.float32)[None, :, None, None]
+    dm = torch.as_tensor(meta.mean, dtype=torch.float32, device=device)[None, :, None, None]
+    ds = torch.as_tensor(meta.std, dtype=torch.float32, device=device)[None, :, None, None]
 
     models = []
     for payload, user in zip(server_payload, shared_data):
-        m = copy.deepcopy(model).to(dtype=torch.float32, device="cpu")
+        m = copy.deepcopy(model).to(dtype=torch.float32, device=device)
         buffers = user["buffers"] if user["buffers"] is not None else payload["buffers"]
         if buffers is None:
             raise NotImplementedError("restatement covers the public/user-buffer (eval mode) cases only")
         m.eval()
         with torch.no_grad():
             for p, s in zip(m.parameters(), payload["parameters"]):
-                p.copy_(s.to("cpu", torch.float32))
+                p.copy_(s.to(device, torch.float32))
             for b, s in zip(m.buffers(), buffers):
-                b.copy_(s.to("cpu", torch.float32))
+                b.copy_(s.to(device, torch.float32))
         models.append(m)
-    data_grads = [[g.to("cpu", torch.float32) for g in user["gradients"]] for user in shared_data]
+    data_grads = [[g.to(device, torch.float32) for g in user["gradients"]] for user in shared_data]
     labels = shared_data[0]["metadata"]["labels"]
     if labels is None:
         raise NotImplementedError("restatement expects provided labels")
-    labels = labels.clone().to("cpu")
+    labels = labels.clone().to(device)
 
     optim = cfg.optim
     n_iter = optim.max_iterations if max_iterations is None else max_iterations
@@ -404,17 +409,17 @@ def run_attack(model, loss_fn, cfg, server_payload, shared_data, initial_data=No
             di.initialize(models)
         num_points = shared_data[0]["metadata"]["num_data_points"]
         if cfg.init == "randn":
-            candidate = torch.randn([num_points, *shape])
+            candidate = torch.randn([num_points, *shape]).to(device)
         elif cfg.init == "zeros":
-            candidate = torch.zeros([num_points, *shape])
+            candidate = torch.zeros([num_points, *shape], device=device)
         else:
             raise NotImplementedError(cfg.init)
         if initial_data is not None:
-            candidate = initial_data.detach().clone().to("cpu", torch.float32)
+            candidate = initial_data.detach().clone().to(device, torch.float32)
         candidate.requires_grad_(True)
         candidate.grad = torch.zeros_like(candidate)
         best = candidate.detach().clone()
-        minimal = torch.as_tensor(float("inf"))
+        minimal = torch.as_tensor(float("inf"), device=device)
         optimizer, scheduler = make_optimizer([candidate], optim.optimizer, optim.step_size, optim.step_size_decay,
                                               optim.warmup, optim.max_iterations)
         t0 = time.time()
@@ -472,7 +477,7 @@ def run_attack(model, loss_fn, cfg, server_payload, shared_data, initial_data=No
             raise NotImplementedError(scoring)
         score, _ = objective_and_task(best, scoring, None)
         score = score.detach()
-        scores.append(score if score.isfinite() else torch.as_tensor(float("inf")))
+        scores.append(score if score.isfinite() else torch.as_tensor(float("inf"), device=device))
     if di is not None:
         di.close()
     scores = torch.stack([s.reshape(()) for s in scores])

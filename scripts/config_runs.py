@@ -120,4 +120,13 @@ if args.only in (None, "5"):
     case = build_text_case(device=dev, full_size=True, seq_len=32)
     run(f"configs[4] BERT-base seq 32 TAG joint attack, {args.its} its", case,
         breaching_amd.get_attack_config("tag", [f"optim.max_iterations={args.its}", "optim.callback=100"]))
+if args.only == "fedavg":
+    # SURVEY section 8 f2 at a BASELINE-sized list: FedAvg user, 2 local SGD steps x 2 images, ResNet-18 / ImageNet -- every local step's
+    # parameter update and the final p_local - p_server are multi-tensor launches (mt_kernel<*>) over the 46.8 MB list
+    from breaching_amd.cases import build_fedavg_case
+
+    model_name = os.environ.get("FEDAVG_MODEL", "resnet18")
+    case = build_fedavg_case(device=dev, model_name=model_name, data_name="ImageNet")
+    run(f"FedAvg multi-step objective (f2): {model_name} ImageNet, 4 images, 2 local steps x 2, invertinggradients, {args.its} its", case,
+        breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={args.its}", "optim.callback=100"]), initial_candidate(case.data_cfg, 4))
 print(json.dumps(out, indent=1))

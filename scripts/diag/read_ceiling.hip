@@ -5,6 +5,7 @@
 // two buffers with eight staged 16-byte loads per lane (plain or non-temporal) and adds them up; `diag_fill` is the producer
 // that leaves its output in L2 / the Infinity Cache the way autograd leaves `rec`.  Built by the probe with hipcc for gfx950.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 namespace {
@@ -55,6 +56,34 @@ int diag_read(const float* a, const float* b, int64_t n_chunks, int32_t grid, in
   if (non_temporal) hipLaunchKernelGGL(diag_read_kernel<true>, dim3(grid), dim3(kBlock), 0, st, a, b, n_chunks, out);
   else hipLaunchKernelGGL(diag_read_kernel<false>, dim3(grid), dim3(kBlock), 0, st, a, b, n_chunks, out);
   return -(int)hipGetLastError();
+}
+
+// `reps` launches of diag_read, each bracketed by the dispatch's own start / stop events (hipExtLaunchKernelGGL -- the timestamps
+// rocprofv3 reports, and the way libbreach_hip.so times kernel A), optionally each behind a diag_fill of `a`.  us_out[reps].
+int diag_read_timed(const float* a, const float* b, int64_t n_chunks, int32_t grid, int32_t non_temporal, float* out, void* stream,
+                    int32_t fill_first, int32_t reps, float* us_out) {
+  if (a == nullptr || b == nullptr || out == nullptr || us_out == nullptr || n_chunks <= 0 || grid <= 0 || reps <= 0 || reps > 1024) return -1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t ev[2048];
+  for (int i = 0; i < 2 * reps; ++i)
+    if (hipEventCreate(&ev[i]) != hipSuccess) return -2;
+  for (int r = 0; r < reps; ++r) {
+    if (fill_first)
+      hipLaunchKernelGGL(diag_fill_kernel, dim3(2048), dim3(kBlock), 0, st, const_cast<float*>(a), (n_chunks * kChunk) >> 2, 0.5f);
+    if (non_temporal)
+      hipExtLaunchKernelGGL(diag_read_kernel<true>, dim3(grid), dim3(kBlock), 0, st, ev[2 * r], ev[2 * r + 1], 0, a, b, n_chunks, out);
+    else
+      hipExtLaunchKernelGGL(diag_read_kernel<false>, dim3(grid), dim3(kBlock), 0, st, ev[2 * r], ev[2 * r + 1], 0, a, b, n_chunks, out);
+  }
+  int rc = -(int)hipGetLastError();
+  if (hipStreamSynchronize(st) != hipSuccess) rc = rc ? rc : -3;
+  for (int r = 0; r < reps; ++r) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]) != hipSuccess) rc = rc ? rc : -4;
+    us_out[r] = ms * 1e3f;
+  }
+  for (int i = 0; i < 2 * reps; ++i) hipEventDestroy(ev[i]);
+  return rc;
 }
 
 int diag_fill(float* p, int64_t n_floats, float value, void* stream) {

@@ -29,6 +29,7 @@ prof() {  # prof <seconds> <name> <pmc-counter or ""> <command...>: rocprofv3 ke
 
 smoke()    { timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; tail -1 $OUT/${TAG}_smoke.log | cut -c1-200; }
 kernels()  { timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q > $OUT/${TAG}_gpu_tests_kernels.log 2>&1; tail -3 $OUT/${TAG}_gpu_tests_kernels.log | cut -c1-250; }
+newtests() { timeout 900 python -m pytest tests -m gpu -x -q -s -k "$NEWTESTS" > $OUT/${TAG}_gpu_tests_new.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests_new.log | cut -c1-300; }
 suite()    { timeout 2400 python -m pytest tests -m gpu -x -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -1 $OUT/${TAG}_gpu_tests.log | cut -c1-200; }
 ceiling()  { timeout 300 python scripts/read_ceiling_probe.py --launches 30 > $OUT/${TAG}_read_ceiling_probe.jsonl 2> $OUT/${TAG}_read_ceiling_probe.err; grep -c . $OUT/${TAG}_read_ceiling_probe.jsonl; grep "kernel A" $OUT/${TAG}_read_ceiling_probe.jsonl | cut -c1-400; tail -2 $OUT/${TAG}_read_ceiling_probe.err | cut -c1-300; }
 mt()       { timeout 200 python scripts/mt_kernel_probe.py --prev build/libbreach_mt_prev.so --launches 30 > $OUT/${TAG}_mt_kernel_probe.jsonl 2> $OUT/${TAG}_mt_kernel_probe.err; cut -c1-700 $OUT/${TAG}_mt_kernel_probe.jsonl; tail -2 $OUT/${TAG}_mt_kernel_probe.err | cut -c1-300; }
@@ -48,7 +49,10 @@ trace_bench()  {
 }
 trace5()   { prof 400 config5_bert_tag "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 5; }
 trace3()   { prof 400 config3_resnet50_seethrough "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 3; }
-trace_fedavg() { prof 400 fedavg_resnet50 "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only fedavg; }
+trace_fedavg() {
+  prof 400 fedavg_resnet18 "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only fedavg --its 100
+  FEDAVG_MODEL=resnet50 prof 400 fedavg_resnet50 "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only fedavg --its 60
+}
 pmc()      {  # pmc <size>: FETCH_SIZE and WRITE_SIZE in separate passes over scripts/pmc_target.py --size <size>
   prof 200 pmc_fetch_$1 FETCH_SIZE python $GRAFT_REPO_ROOT/scripts/pmc_target.py --size $1
   prof 200 pmc_write_$1 WRITE_SIZE python $GRAFT_REPO_ROOT/scripts/pmc_target.py --size $1
@@ -58,7 +62,12 @@ pmc_resnet50() { pmc resnet50; }
 pmc_resnet18() { pmc resnet18; }
 pmc_mt()       { pmc mt_resnet50; pmc mt_bert; }
 configs()  { timeout 1500 python scripts/config_runs.py > $OUT/${TAG}_config_runs_same_process.log 2>&1; tail -12 $OUT/${TAG}_config_runs_same_process.log | cut -c1-400; }
-control()  { timeout 1500 python scripts/config_runs.py --only control > $OUT/${TAG}_same_gpu_torch_control.log 2>&1; tail -30 $OUT/${TAG}_same_gpu_torch_control.log | cut -c1-300; }
+control()  { timeout 900 python tests/control_same_gpu_torch.py --out $OUT/${TAG}_control_same_gpu_torch.json > $OUT/${TAG}_control_same_gpu_torch.log 2>&1; tail -14 $OUT/${TAG}_control_same_gpu_torch.log | cut -c1-260; }
+stepprior_trace() {
+  prof 200 step_prior_probe "" python $GRAFT_REPO_ROOT/scripts/step_prior_probe.py --launches 20
+  BREACH_HIP_LIB=$PREV prof 200 step_prior_probe_prev "" python $GRAFT_REPO_ROOT/scripts/step_prior_probe.py --launches 20
+}
+mt_trace() { prof 200 mt_kernel_probe "" python $GRAFT_REPO_ROOT/scripts/mt_kernel_probe.py --launches 20; }
 
 set -x
 for stage in "$@"; do $stage; done

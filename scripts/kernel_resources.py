@@ -14,8 +14,8 @@ nothing on this path is GEMM-shaped).
 in a kernel that runs thousands of wavefronts, the whole cost of one that runs a wavefront per SIMD (how kernels E and F
 were found in round 4).
 
-    python scripts/kernel_resources.py [--out profiles/r4_kernel_resources.txt] [--isa --isa-out profiles/r4_kernel_isa_census.txt]
-                                       [--loops --loops-out profiles/r4_kernel_loop_census.txt]
+    python scripts/kernel_resources.py [--out profiles/r5_kernel_resources.txt] [--isa --isa-out profiles/r5_kernel_isa_census.txt]
+                                       [--loops --loops-out profiles/r5_kernel_loop_census.txt]
 """
 import argparse
 import os
@@ -30,6 +30,16 @@ sys.path.insert(0, ROOT)
 FIELDS = [("VGPRs", "vgpr"), ("AGPRs", "agpr"), ("TotalSGPRs", "sgpr"), ("ScratchSize [bytes/lane]", "scratch"),
           ("Occupancy [waves/SIMD]", "waves"), ("SGPRs Spill", "sgpr_spill"), ("VGPRs Spill", "vgpr_spill"),
           ("LDS Size [bytes/block]", "lds")]
+
+
+def compiler_id():
+    """One line naming the hipcc the tables came from: instruction scheduling and register allocation differ between ROCm
+    releases, so the committed tables are compared byte for byte only under the compiler that wrote them (tests/test_abi.py)."""
+    from breaching_amd.build import _hipcc
+
+    out = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout
+    lines = [ln.strip() for ln in out.splitlines() if "HIP version" in ln or "clang version" in ln]
+    return "# compiler: " + "; ".join(lines)
 
 
 def demangle(names):
@@ -175,7 +185,7 @@ def loop_census():
 
 
 def render_loops(rows):
-    lines = ["# loops of the generated gfx950 code that load from global memory (scripts/kernel_resources.py --loops)",
+    lines = [compiler_id(), "# loops of the generated gfx950 code that load from global memory (scripts/kernel_resources.py --loops)",
              "# loads / stores / s_waitcnt vmcnt(0) / s_waitcnt vmcnt(n > 0) per trip; few loads with a full wait per trip = one serial round trip per trip",
              f"{'kernel':50s} {'loop':>10s} {'depth':>5s} {'loads':>6s} {'stores':>6s} {'wait0':>6s} {'waitN':>6s} {'instr':>6s}"]
     for r in rows:
@@ -198,7 +208,7 @@ def isa_census():
 
 def render_isa(census):
     keys = ["instructions", "ld128", "ld64", "ld32", "ld_nt", "st128", "st64", "st32", "st_nt", "atomics", "lds", "xlane", "mfma", "scratch"]
-    lines = ["# instruction census of the gfx950 assembly (hipcc -O3 -S --cuda-device-only), one line per kernel instantiation",
+    lines = [compiler_id(), "# instruction census of the gfx950 assembly (hipcc -O3 -S --cuda-device-only), one line per kernel instantiation",
              "# ld/st = global loads / stores by width in bits; *_nt = of those, with the non-temporal bit; xlane = DPP / permute / readlane",
              f"{'kernel':58s} " + " ".join(f"{k:>8s}" for k in keys)]
     for name, row in census.items():
@@ -209,7 +219,7 @@ def render_isa(census):
 
 def render(rows):
     head = f"{'source':24s} {'kernel':58s} {'VGPR':>5s} {'AGPR':>5s} {'SGPR':>5s} {'scratch':>8s} {'spills':>7s} {'LDS B':>7s} {'waves/SIMD':>10s}"
-    lines = ["# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage, one line per kernel instantiation",
+    lines = [compiler_id(), "# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage, one line per kernel instantiation",
              "# (scripts/kernel_resources.py; 512 VGPRs per SIMD lane -> 8 waves/SIMD needs <= 64)", head]
     for r in rows:
         lines.append(f"{r['source']:24s} {r['kernel'][:58]:58s} {r['vgpr']:5d} {r['agpr']:5d} {r['sgpr']:5d} {r['scratch']:8d} "

