@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from . import build as _build
 
 # ---- constants mirrored from include/breach_hip.h (checked against the library in tests) -------------------------
-BH_ABI_VERSION = 5
+BH_ABI_VERSION = 6
 BH_GM_CHUNK = 4096
 BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
@@ -19,7 +19,7 @@ BH_GM_DEFAULT_ROWS = 512
 BH_GM_STAT_WORDS = 12
 BH_PRIOR_MAX_GRID = 1024
 BH_BN_MAX_LAYERS = 448
-BH_MT_MAX_PTRS = 128
+BH_MT_MAX_PTRS = 112
 BH_BN_TILE = 4096
 BH_PRIOR_PARTIAL_STRIDE = 2
 BH_STATE_WORDS = 16

@@ -20,13 +20,33 @@ namespace {
 
 using bh::kBlock;
 
-struct MtPtrs {
+enum MtOp { kAxpy = 0, kAxpyMinus = 1, kScale = 2, kPatch = 3 };
+
+// Pointer lists travel in the kernel-argument segment (as kernel A's do): three lists of BH_MT_MAX_PTRS (112) pointers for the
+// one three-list form, (a + alpha b) - c; every other form reads at most two lists, and then TWO adjacent base groups ride in one
+// launch (2 x 224 pointers = 3584 bytes, the size of kernel A's block).  The gradient lists of ResNet-50 (161 tensors) and
+// BERT-base (201) are one launch per call that way instead of two (round 4: 128 per list and launch for every form) -- the launch
+// boundary in the middle of a 50 us call was most of what separated this kernel from kernel A's backward on the same bytes
+// (profiles/r5_mt_kernel_probe.jsonl).
+struct MtPtrs3 {
+  static constexpr int kGroups = 1;
   const float* a[BH_MT_MAX_PTRS];
   const float* b[BH_MT_MAX_PTRS];
   const float* c[BH_MT_MAX_PTRS];
 };
-
-enum MtOp { kAxpy = 0, kAxpyMinus = 1, kScale = 2, kPatch = 3 };
+struct MtPtrs2 {
+  static constexpr int kGroups = 2;
+  const float* a[2 * BH_MT_MAX_PTRS];
+  const float* b[2 * BH_MT_MAX_PTRS];
+};
+template <int OP>
+struct MtPtrsFor {
+  using type = MtPtrs2;
+};
+template <>
+struct MtPtrsFor<kAxpyMinus> {
+  using type = MtPtrs3;
+};
 
 // op(a, b, c) per element.  k0 / k1: alpha (axpy, scale) or the two direction coefficients (patch).
 template <int OP>
@@ -118,14 +138,16 @@ __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const floa
 // `coef`: device pair overriding (k0, k1) when non-NULL (patch).  A NULL `a` pointer reads as zeros (scale of a missing
 // upstream gradient).
 template <int OP, bool NT>
-__global__ __launch_bounds__(kBlock) void mt_kernel(MtPtrs ptrs, int tensor_base, const float* __restrict__ c_flat,
+__global__ __launch_bounds__(kBlock) void mt_kernel(typename MtPtrsFor<OP>::type ptrs, int tensor_base, const float* __restrict__ c_flat,
                                                     const bh_gm_chunk* __restrict__ chunks, int chunk_base, float k0,
                                                     float k1, const float* __restrict__ coef, float* __restrict__ out_flat) {
   const bh_gm_chunk ch = chunks[chunk_base + blockIdx.x];
   const int t = ch.tensor - tensor_base;
   const float* __restrict__ a = ptrs.a[t];
   const float* __restrict__ b = ptrs.b[t];
-  const float* __restrict__ c = c_flat ? c_flat + ch.flat_off : ptrs.c[t];
+  const float* __restrict__ c;
+  if constexpr (OP == kAxpyMinus) c = ptrs.c[t];
+  else c = c_flat ? c_flat + ch.flat_off : nullptr;
   float* __restrict__ o = out_flat + ch.flat_off;
   if (coef) {  // patch: the host value k0 is the multiplier of the device coefficient pair
     k1 = k0 * coef[1];
@@ -133,7 +155,7 @@ __global__ __launch_bounds__(kBlock) void mt_kernel(MtPtrs ptrs, int tensor_base
   }
   constexpr bool needs_b = OP != kScale, needs_c = OP == kAxpyMinus || OP == kPatch;
   const float* __restrict__ bp = needs_b ? b + ch.tensor_off : nullptr;
-  const float* __restrict__ cp = needs_c ? (c_flat ? c : c + ch.tensor_off) : nullptr;
+  const float* __restrict__ cp = needs_c ? (OP == kAxpyMinus ? c + ch.tensor_off : c) : nullptr;
   if (a)  // uniform over the workgroup
     mt_chunk<OP, true, NT>(a + ch.tensor_off, bp, cp, o, ch.len, k0, k1);
   else
@@ -145,11 +167,16 @@ bool ok_ptr(const void* p, bool allow_null) {
   return (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
 }
 
-bool fill(MtPtrs& out, const void* const* a, const void* const* b, const void* const* c, int n_tensors, int g,
-          bool a_nullable) {
-  const int base = g * BH_MT_MAX_PTRS;
-  const int cnt = (n_tensors - base) < BH_MT_MAX_PTRS ? (n_tensors - base) : BH_MT_MAX_PTRS;
-  for (int i = 0; i < BH_MT_MAX_PTRS; ++i) out.a[i] = out.b[i] = out.c[i] = nullptr;
+// Pointers of launch `g` (P::kGroups base groups of BH_MT_MAX_PTRS tensors each); false on a misaligned / unexpected null pointer.
+template <class P>
+bool fill(P& out, const void* const* a, const void* const* b, const void* const* c, int n_tensors, int g, bool a_nullable) {
+  constexpr int kPer = P::kGroups * BH_MT_MAX_PTRS;
+  const int base = g * kPer;
+  const int cnt = (n_tensors - base) < kPer ? (n_tensors - base) : kPer;
+  for (int i = 0; i < kPer; ++i) {
+    out.a[i] = out.b[i] = nullptr;
+    if constexpr (P::kGroups == 1) out.c[i] = nullptr;
+  }
   for (int i = 0; i < cnt; ++i) {
     if (!ok_ptr(a[base + i], a_nullable)) return false;
     out.a[i] = static_cast<const float*>(a[base + i]);
@@ -157,9 +184,11 @@ bool fill(MtPtrs& out, const void* const* a, const void* const* b, const void* c
       if (!ok_ptr(b[base + i], false)) return false;
       out.b[i] = static_cast<const float*>(b[base + i]);
     }
-    if (c) {
-      if (!ok_ptr(c[base + i], false)) return false;
-      out.c[i] = static_cast<const float*>(c[base + i]);
+    if constexpr (P::kGroups == 1) {
+      if (c) {
+        if (!ok_ptr(c[base + i], false)) return false;
+        out.c[i] = static_cast<const float*>(c[base + i]);
+      }
     }
   }
   return true;
@@ -173,9 +202,11 @@ int run_mt(int32_t n_tensors, const void* const* a, const void* const* b, const 
       out_flat == nullptr || (reinterpret_cast<uintptr_t>(out_flat) & 15u) != 0)
     return BH_EINVAL;
   if (c_flat != nullptr && (reinterpret_cast<uintptr_t>(c_flat) & 15u) != 0) return BH_EINVAL;
-  const int groups = bh_mt_num_groups(n_tensors);
-  for (int g = 0; g < groups; ++g) {  // validate everything before anything is enqueued
-    MtPtrs probe;
+  using P = typename MtPtrsFor<OP>::type;
+  const int base_groups = bh_mt_num_groups(n_tensors);  // `group_chunk_begin` is laid out for these (BH_MT_MAX_PTRS tensors each)
+  const int launches = (base_groups + P::kGroups - 1) / P::kGroups;
+  for (int g = 0; g < launches; ++g) {  // validate everything before anything is enqueued
+    P probe;
     if (!fill(probe, a, b, c, n_tensors, g, a_nullable)) return BH_EINVAL;
   }
   hipStream_t st = bh::as_stream(stream);
@@ -186,17 +217,19 @@ int run_mt(int32_t n_tensors, const void* const* a, const void* const* b, const 
   // profiles/r4_mt_kernel_probe_nt.jsonl).
   constexpr int kOperands = OP == kScale ? 1 : (OP == kAxpy ? 2 : 3);
   const bool stream_loads = n_chunks * (int64_t)BH_GM_CHUNK * 4 * (kOperands + 1) > (int64_t)BH_GM_CACHE_AUTO_BYTES;
-  for (int g = 0; g < groups; ++g) {
-    const int begin = group_chunk_begin[g], n = group_chunk_begin[g + 1] - begin;
+  for (int g = 0; g < launches; ++g) {
+    const int first = g * P::kGroups, last = (first + P::kGroups) < base_groups ? (first + P::kGroups) : base_groups;
+    const int begin = group_chunk_begin[first], n = group_chunk_begin[last] - begin;
     if (n <= 0) continue;
-    MtPtrs ptrs;
+    P ptrs;
     fill(ptrs, a, b, c, n_tensors, g, a_nullable);
+    const int tensor_base = g * P::kGroups * BH_MT_MAX_PTRS;
     if (stream_loads)
-      hipLaunchKernelGGL((mt_kernel<OP, true>), dim3(n), dim3(kBlock), 0, st, ptrs, g * BH_MT_MAX_PTRS, c_flat, chunks_dev, begin,
-                         k0, k1, coef, out_flat);
+      hipLaunchKernelGGL((mt_kernel<OP, true>), dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, c_flat, chunks_dev, begin, k0, k1, coef,
+                         out_flat);
     else
-      hipLaunchKernelGGL((mt_kernel<OP, false>), dim3(n), dim3(kBlock), 0, st, ptrs, g * BH_MT_MAX_PTRS, c_flat, chunks_dev, begin,
-                         k0, k1, coef, out_flat);
+      hipLaunchKernelGGL((mt_kernel<OP, false>), dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, c_flat, chunks_dev, begin, k0, k1, coef,
+                         out_flat);
     const int rc = bh::launch_status();
     if (rc != 0) return rc;
   }

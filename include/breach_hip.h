@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BH_ABI_VERSION 5
+#define BH_ABI_VERSION 6
 #define BH_EINVAL (-1)
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -324,8 +324,9 @@ int bh_ln_bwd_bwd(const float* u, const float* s, const float* t, const float* g
  * Multi-tensor elementwise kernels over per-parameter lists (FedAvg unroll, Pearlmutter offset) and batch kernels
  * ---------------------------------------------------------------------------------------------------------------- */
 
-/* Pointers per operand list and launch (three lists travel in the kernel arguments). */
-#define BH_MT_MAX_PTRS 128
+/* Tensors per base launch group.  Three pointer lists of this length travel in the kernel arguments of the one three-list form
+ * ((a + alpha b) - c); the forms with at most two lists put two adjacent base groups (224 tensors) into one launch. */
+#define BH_MT_MAX_PTRS 112
 int32_t bh_mt_num_groups(int32_t n_tensors);
 /* Like bh_gm_group_bounds for launch groups of BH_MT_MAX_PTRS tensors: group_chunk_begin[bh_mt_num_groups + 1]. */
 int bh_mt_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_t n_chunks, int32_t* group_chunk_begin);

@@ -211,7 +211,7 @@ def test_no_compatibility_layers_in_the_product():
 
 def test_forward_rows_and_mt_group_bounds_host_arithmetic(hip_lib):
     """Persistent-grid sizing of kernel A (bh_gm_fwd_rows with its rows-cap ARGUMENT -- the library keeps no tuning state) and
-    the 128-tensor launch groups of the multi-tensor kernels (bh_mt_group_bounds): pure host arithmetic."""
+    the 112-tensor base launch groups of the multi-tensor kernels (bh_mt_group_bounds): pure host arithmetic."""
     from ctypes import byref, c_int32, c_int64
 
     from breaching_amd import _lib
@@ -249,13 +249,13 @@ def test_forward_rows_and_mt_group_bounds_host_arithmetic(hip_lib):
     # the tuning knobs of round 3 are gone from the ABI: nothing in the library is mutable from outside a launch
     for gone in ("bh_gm_set_rows_cap", "bh_bn_set_grid_cap", "bh_bn_set_finalize_block", "bh_bn_set_load_depth"):
         assert not hasattr(hip_lib, gone), gone
-    # multi-tensor launch groups: 300 small tensors -> 3 groups of 128 / 128 / 44 tensors, one chunk each
+    # multi-tensor base launch groups: 300 small tensors -> 3 groups of 112 / 112 / 76 tensors, one chunk each
     numel = [10 + i for i in range(300)]
     chunks, n = table(numel)
-    assert hip_lib.bh_mt_num_groups(300) == 3 and hip_lib.bh_mt_num_groups(0) == 0 and hip_lib.bh_mt_num_groups(128) == 1
+    assert hip_lib.bh_mt_num_groups(300) == 3 and hip_lib.bh_mt_num_groups(0) == 0 and hip_lib.bh_mt_num_groups(112) == 1 and hip_lib.bh_mt_num_groups(113) == 2
     bounds = (c_int32 * 4)()
     assert hip_lib.bh_mt_group_bounds(300, chunks, n, bounds) == 0
-    assert list(bounds) == [0, 128, 256, 300]
+    assert list(bounds) == [0, 112, 224, 300]
     assert all(chunks[i].tensor == i for i in range(n))
     assert hip_lib.bh_mt_group_bounds(300, chunks, n, None) == -1
 

@@ -543,15 +543,18 @@ def test_psnr_on_device_matches_reference_golden_and_c_oracle(golden_dir, kernel
     assert np.isnan(psnr_on_device(torch.tensor(a, device=_dev()), torch.tensor(b, device=_dev()), clip=False)[0].item())
 
 
-def test_multi_tensor_axpy_scale_and_fedavg_step_function(hip_lib):
+@pytest.mark.parametrize("extra,base_groups", [(140, 2), (240, 3)])
+def test_multi_tensor_axpy_scale_and_fedavg_step_function(extra, base_groups, hip_lib):
     """bh_mt_axpy / bh_mt_scale against torch, bit for bit (mul, add and sub round separately like torch's ops), over a ragged
-    list longer than one launch group (> 128 tensors), through the autograd node the FedAvg unroll uses."""
+    list longer than one base launch group (> 112 tensors), through the autograd node the FedAvg unroll uses.  146 tensors: the
+    two-list forms (a + alpha b, alpha a) take ONE launch of two base groups, the three-list form ((a + alpha b) - c) two; 246
+    tensors: two and three launches."""
     from breaching_amd.gm import ListLayout, _LocalStepFunction
 
     gen = torch.Generator().manual_seed(9)
-    shapes = [(5000,), (3,), (4096,), (33, 65), (1,), (2, 4100)] + [(50 + i,) for i in range(140)]
+    shapes = [(5000,), (3,), (4096,), (33, 65), (1,), (2, 4100)] + [(50 + i,) for i in range(extra)]
     layout = ListLayout(shapes, _dev())
-    assert hip_lib.bh_mt_num_groups(len(shapes)) == 2
+    assert hip_lib.bh_mt_num_groups(len(shapes)) == base_groups
     params = [torch.randn(s, generator=gen).to(_dev()).requires_grad_(True) for s in shapes]
     grads = [torch.randn(s, generator=gen).to(_dev()).requires_grad_(True) for s in shapes]
     base = [torch.randn(s, generator=gen).to(_dev()) for s in shapes]
