@@ -682,24 +682,23 @@ int bh_prior_tv_norm(const float* x, int32_t B, int32_t H, int32_t W, float tv_s
   const float norm_grad_coef = norm_scale != 0.f ? (float)((double)norm_scale / ((double)pixels * 3)) : 0.f;
   const bool pq1 = inner_exp == 1.f && outer_exp == 1.f;
   hipStream_t st = bh::as_stream(stream);
-  // 16-byte path: every row of every plane starts on a 16-byte boundary.  Small images (fewer quads than one 256-thread workgroup
-  // per CU would take) run one wavefront per workgroup so that B = 1 at 224 x 224 still spreads over 196 CUs.
-  const bool vec4 = pq1 && (W & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_out)) & 15u) == 0;
+  // 16-byte path for batches (at least one 256-thread workgroup of quads per CU: B >= 6 at 224 x 224): measured with rocprofv3 on
+  // 8 x 3 x 224 x 224, 7.25 us against 8.1 us for the one-pixel-per-thread kernel alone (8.4 vs 8.2-8.5 us inside the see-through
+  // loop); at B = 1 the launch is latency-bound and fewer, fatter threads LOSE (one wavefront per workgroup of quads: 5.1 us against
+  // 4.1-4.3 us), so single images stay on the scalar kernel (profiles/r5_step_prior_probe_kernel_summary.csv).
+  const int64_t quads = pixels >> 2;
+  const bool vec4 = pq1 && (W & 3) == 0 && quads >= (int64_t)256 * kBlock &&
+                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(grad_out)) & 15u) == 0;
   int grid;
   if (vec4) {
-    const int64_t quads = pixels >> 2;
-    const bool wide = quads >= (int64_t)256 * kBlock;
-    const int threads = wide ? kBlock : bh::kWave;
-    const int64_t blocks = (quads + threads - 1) / threads;
+    const int64_t blocks = (quads + kBlock - 1) / kBlock;
     grid = (int)(blocks < BH_PRIOR_MAX_GRID ? blocks : BH_PRIOR_MAX_GRID);
-#define BH_TV_LAUNCH(OPP, THREADS)                                                                                     \
-  hipLaunchKernelGGL((tv_norm_vec4_kernel<OPP, THREADS>), dim3(grid), dim3(THREADS), 0, st, x, B, H, W, tv_coef,       \
-                     inner_exp, outer_exp, eps, norm_val_coef, norm_grad_coef, norm_p, grad_out, partials_dev)
-    if (wide && double_opponents) BH_TV_LAUNCH(true, kBlock);
-    else if (wide) BH_TV_LAUNCH(false, kBlock);
-    else if (double_opponents) BH_TV_LAUNCH(true, bh::kWave);
-    else BH_TV_LAUNCH(false, bh::kWave);
-#undef BH_TV_LAUNCH
+    if (double_opponents)
+      hipLaunchKernelGGL((tv_norm_vec4_kernel<true, kBlock>), dim3(grid), dim3(kBlock), 0, st, x, B, H, W, tv_coef, inner_exp, outer_exp, eps,
+                         norm_val_coef, norm_grad_coef, norm_p, grad_out, partials_dev);
+    else
+      hipLaunchKernelGGL((tv_norm_vec4_kernel<false, kBlock>), dim3(grid), dim3(kBlock), 0, st, x, B, H, W, tv_coef, inner_exp, outer_exp, eps,
+                         norm_val_coef, norm_grad_coef, norm_p, grad_out, partials_dev);
   } else {
     const int64_t blocks = (pixels + kBlock - 1) / kBlock;
     grid = (int)(blocks < BH_PRIOR_MAX_GRID ? blocks : BH_PRIOR_MAX_GRID);

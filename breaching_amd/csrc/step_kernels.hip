@@ -174,13 +174,13 @@ __global__ __launch_bounds__(kBlock) void candidate_step_kernel(const Word* __re
 // a channel and the box of its four elements is one (lo, hi) pair, looked up once.  All loads of a float4 group are issued before
 // the first use.  Element arithmetic = step_elem, i.e. bit-identical to the scalar kernel.  (At BASELINE configs[2], 8 x 3 x 224 x
 // 224, the scalar kernel moved ~43-48 MB in 11.4-11.9 us with 4-byte accesses, profiles/r4_kernel_isa_census.txt.)
+template <bool HAS_REG, bool HAS_NOISE>  // resolved per launch: `p ? p4[i] : zero` on a float4 is scalarised into four guarded dword loads
 __global__ __launch_bounds__(kBlock) void candidate_step_vec4_kernel(const Word* __restrict__ st, const double* __restrict__ sched,
                                                                      bh_step_params P, float* __restrict__ x,
                                                                      const float* __restrict__ g,
                                                                      const float* __restrict__ g_reg,
                                                                      const float* __restrict__ noise, float* __restrict__ m,
                                                                      float* __restrict__ v, float* __restrict__ best) {
-  const StepScalars k = step_scalars(st, sched, P, noise != nullptr);
   const int64_t n4 = P.n >> 2, plane4 = P.plane >> 2;
   float4* __restrict__ x4 = reinterpret_cast<float4*>(x);
   float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
@@ -190,16 +190,25 @@ __global__ __launch_bounds__(kBlock) void candidate_step_vec4_kernel(const Word*
   const float4* __restrict__ r4 = reinterpret_cast<const float4*>(g_reg);
   const float4* __restrict__ z4 = reinterpret_cast<const float4*>(noise);
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (int64_t)gridDim.x * kBlock) {
-    const float4 gv = g4[i];
-    const float4 rv = r4 ? r4[i] : zero;
-    const float4 zv = z4 ? z4[i] : zero;
-    float4 xv = x4[i], mv = m4[i], vv = v4[i];
+  // The launch covers the tensor in one sweep whenever n / 4 <= 2048 * 256 (every BASELINE candidate): the thread's six operand
+  // loads are issued FIRST and the iteration scalars -- two dependent loads, state word -> schedule row -- are fetched while they
+  // are in flight, instead of one round trip after the other in front of a 5-10 us kernel.
+  int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool mine = i < n4;
+  const int64_t i0 = mine ? i : 0;
+  float4 gv = g4[i0];
+  float4 rv = zero, zv = zero;
+  if constexpr (HAS_REG) rv = r4[i0];
+  if constexpr (HAS_NOISE) zv = z4[i0];
+  float4 xv = x4[i0], mv = m4[i0], vv = v4[i0];
+  const StepScalars k = step_scalars(st, sched, P, HAS_NOISE);
+  if (!mine) return;
+  for (;;) {
     const int c = P.boxed ? (int)((i / plane4) % P.channels) : 0;
     const float lo = P.lo[c], hi = P.hi[c];
     float ge[4] = {gv.x, gv.y, gv.z, gv.w};
-    if (r4) ge[0] += rv.x, ge[1] += rv.y, ge[2] += rv.z, ge[3] += rv.w;
-    if (z4) {  // optimization_based_attack.py:167-170
+    if constexpr (HAS_REG) ge[0] += rv.x, ge[1] += rv.y, ge[2] += rv.z, ge[3] += rv.w;
+    if constexpr (HAS_NOISE) {  // optimization_based_attack.py:167-170
       ge[0] = fmaf(k.noise_coef, zv.x, ge[0]), ge[1] = fmaf(k.noise_coef, zv.y, ge[1]);
       ge[2] = fmaf(k.noise_coef, zv.z, ge[2]), ge[3] = fmaf(k.noise_coef, zv.w, ge[3]);
     }
@@ -211,6 +220,12 @@ __global__ __launch_bounds__(kBlock) void candidate_step_vec4_kernel(const Word*
     m4[i] = mv;
     v4[i] = vv;
     if (k.improved) b4[i] = xv;
+    i += (int64_t)gridDim.x * kBlock;
+    if (i >= n4) break;
+    gv = g4[i];
+    if constexpr (HAS_REG) rv = r4[i];
+    if constexpr (HAS_NOISE) zv = z4[i];
+    xv = x4[i], mv = m4[i], vv = v4[i];
   }
 }
 
@@ -270,9 +285,14 @@ int bh_candidate_step(const void* state_dev, const double* sched_dev, const bh_s
   const int64_t units = vec4 ? P.n >> 2 : P.n;
   int64_t blocks = (units + kBlock - 1) / kBlock;
   if (blocks > 2048) blocks = 2048;
-  if (vec4)
-    hipLaunchKernelGGL(candidate_step_vec4_kernel, dim3((int)blocks), dim3(kBlock), 0, bh::as_stream(stream),
-                       static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, noise, m, v, best);
+#define BH_STEP_VEC4(HAS_REG, HAS_NOISE)                                                                                \
+  hipLaunchKernelGGL((candidate_step_vec4_kernel<HAS_REG, HAS_NOISE>), dim3((int)blocks), dim3(kBlock), 0,             \
+                     bh::as_stream(stream), static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, noise, m, v, best)
+  if (vec4 && g_reg && noise) BH_STEP_VEC4(true, true);
+  else if (vec4 && g_reg) BH_STEP_VEC4(true, false);
+  else if (vec4 && noise) BH_STEP_VEC4(false, true);
+  else if (vec4) BH_STEP_VEC4(false, false);
+#undef BH_STEP_VEC4
   else
     hipLaunchKernelGGL(candidate_step_kernel, dim3((int)blocks), dim3(kBlock), 0, bh::as_stream(stream),
                        static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, noise, m, v,

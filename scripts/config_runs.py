@@ -126,7 +126,8 @@ if args.only == "fedavg":
     from breaching_amd.cases import build_fedavg_case
 
     model_name = os.environ.get("FEDAVG_MODEL", "resnet18")
-    case = build_fedavg_case(device=dev, model_name=model_name, data_name="ImageNet")
+    # ResNet-50 at its random init diverges under two plain-SGD steps of 0.05 (non-finite objective at the first iteration)
+    case = build_fedavg_case(device=dev, model_name=model_name, data_name="ImageNet", lr=float(os.environ.get("FEDAVG_LR", "0.05")))
     run(f"FedAvg multi-step objective (f2): {model_name} ImageNet, 4 images, 2 local steps x 2, invertinggradients, {args.its} its", case,
         breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={args.its}", "optim.callback=100"]), initial_candidate(case.data_cfg, 4))
 print(json.dumps(out, indent=1))

@@ -32,7 +32,7 @@ kernels()  { timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q
 newtests() { timeout 900 python -m pytest tests -m gpu -x -q -s -k "$NEWTESTS" > $OUT/${TAG}_gpu_tests_new.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests_new.log | cut -c1-300; }
 suite()    { timeout 2400 python -m pytest tests -m gpu -x -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -1 $OUT/${TAG}_gpu_tests.log | cut -c1-200; }
 ceiling()  { timeout 300 python scripts/read_ceiling_probe.py --launches 30 > $OUT/${TAG}_read_ceiling_probe.jsonl 2> $OUT/${TAG}_read_ceiling_probe.err; grep -c . $OUT/${TAG}_read_ceiling_probe.jsonl; grep "kernel A" $OUT/${TAG}_read_ceiling_probe.jsonl | cut -c1-400; tail -2 $OUT/${TAG}_read_ceiling_probe.err | cut -c1-300; }
-mt()       { timeout 200 python scripts/mt_kernel_probe.py --prev build/libbreach_mt_prev.so --launches 30 > $OUT/${TAG}_mt_kernel_probe.jsonl 2> $OUT/${TAG}_mt_kernel_probe.err; cut -c1-700 $OUT/${TAG}_mt_kernel_probe.jsonl; tail -2 $OUT/${TAG}_mt_kernel_probe.err | cut -c1-300; }
+mt()       { timeout 200 python scripts/mt_kernel_probe.py --launches 30 > $OUT/${TAG}_mt_kernel_probe.jsonl 2> $OUT/${TAG}_mt_kernel_probe.err; cut -c1-700 $OUT/${TAG}_mt_kernel_probe.jsonl; tail -2 $OUT/${TAG}_mt_kernel_probe.err | cut -c1-300; }
 stepprior() {
   timeout 120 python scripts/step_prior_probe.py > $OUT/${TAG}_step_prior_probe.jsonl 2> $OUT/${TAG}_step_prior_probe.err
   BREACH_HIP_LIB=$PREV timeout 120 python scripts/step_prior_probe.py >> $OUT/${TAG}_step_prior_probe.jsonl 2>> $OUT/${TAG}_step_prior_probe.err
@@ -51,7 +51,7 @@ trace5()   { prof 400 config5_bert_tag "" python $GRAFT_REPO_ROOT/scripts/config
 trace3()   { prof 400 config3_resnet50_seethrough "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 3; }
 trace_fedavg() {
   prof 400 fedavg_resnet18 "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only fedavg --its 100
-  FEDAVG_MODEL=resnet50 prof 400 fedavg_resnet50 "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only fedavg --its 60
+  FEDAVG_MODEL=resnet50 FEDAVG_LR=0.0005 prof 400 fedavg_resnet50 "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only fedavg --its 60
 }
 pmc()      {  # pmc <size>: FETCH_SIZE and WRITE_SIZE in separate passes over scripts/pmc_target.py --size <size>
   prof 200 pmc_fetch_$1 FETCH_SIZE python $GRAFT_REPO_ROOT/scripts/pmc_target.py --size $1

@@ -9,7 +9,8 @@ import csv, os, sys, collections
 OURS = ("gm_fwd_kernel", "gm_bwd_kernel", "gm_finalize_kernel", "tv_norm_kernel", "candidate_step_kernel", "loss_commit_kernel",
         "bn_sums_kernel", "bn_finalize_kernel", "bn_bwd_kernel", "bn_bwd_acc_kernel", "mt_kernel", "orthogonality_kernel", "psnr_mse_kernel",
         "grad_sumsq", "gm_pack_kernel", "state_reset", "bn_eval_fwd_kernel", "bn_eval_bwd_kernel", "bn_eval_bwd_bwd_kernel",
-        "bn_eval_combine_kernel", "ln_fwd_kernel", "ln_bwd_", "grad_norm_finalize_kernel", "psnr_finalize_kernel")
+        "bn_eval_combine_kernel", "ln_fwd_kernel", "ln_bwd_", "grad_norm_finalize_kernel", "psnr_finalize_kernel", "tv_norm_vec4_kernel",
+        "candidate_step_vec4_kernel")
 src, out = sys.argv[1], sys.argv[2]
 counter = sys.argv[3] if len(sys.argv) > 3 else None
 files = {f: os.path.join(src, f) for f in os.listdir(src)}
@@ -23,11 +24,14 @@ def short(name):
 trace = next((p for f, p in files.items() if f.endswith("kernel_trace.csv")), None)
 if trace:
     per = collections.defaultdict(list)
+    by_grid = collections.defaultdict(list)  # our kernels again, split by launch size: one probe run often covers several list sizes
     first, last = None, None
     with open(trace) as f:
         for row in csv.DictReader(f):
             s, e = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
             per[row["Kernel_Name"]].append(e - s)
+            if "Grid_Size_X" in row and any(k in row["Kernel_Name"] for k in OURS):
+                by_grid[(row["Kernel_Name"], int(row["Grid_Size_X"]) // max(int(row.get("Workgroup_Size_X") or 1), 1))].append(e - s)
             first = s if first is None else min(first, s)
             last = e if last is None else max(last, e)
     total = sum(sum(v) for v in per.values())
@@ -43,6 +47,13 @@ if trace:
         for name, d in rows:
             if any(k in name for k in OURS):
                 f.write(f"{short(name):70s} calls={len(d):5d} avg={sum(d)/len(d)/1e3:8.2f}us min={min(d)/1e3:8.2f}us max={max(d)/1e3:8.2f}us\n")
+    if by_grid:
+        with open(out + "_kernel_by_grid.csv", "w") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "workgroups", "calls", "avg_us", "median_us", "min_us", "max_us"])
+            for (name, wgs), d in sorted(by_grid.items(), key=lambda kv: (kv[0][0], kv[0][1])):
+                d = sorted(d)
+                w.writerow([short(name), wgs, len(d), round(sum(d) / len(d) / 1e3, 3), round(d[len(d) // 2] / 1e3, 3), round(d[0] / 1e3, 3), round(d[-1] / 1e3, 3)])
     print(open(out + "_kernel_summary.txt").read())
 
 cc = next((p for f, p in files.items() if f.endswith("counter_collection.csv")), None)

@@ -194,9 +194,10 @@ def test_tv_norm_matches_c_oracle(shape, opp, kernels_oracle, hip_lib):
 
 @pytest.mark.parametrize("shape,opp", [((1, 3, 224, 224), False), ((8, 3, 224, 224), False), ((8, 3, 224, 224), True), ((2, 3, 12, 16), True)])
 def test_tv_norm_16_byte_path_gradient_is_bit_identical_to_the_scalar_path(shape, opp, hip_lib):
-    """Kernel C with four pixels per thread (W % 4 == 0, aligned planes; one wavefront per workgroup for small images, 256 threads
-    for batches) against the one-pixel-per-thread kernel, which a 4-byte-offset view of the same data is routed to: the gradient
-    must agree bit for bit (same per-pixel statements), the two values to fp64 summation order."""
+    """Kernel C with four pixels per thread (p = q = 1, W % 4 == 0, aligned planes, batches of at least 65 536 quads -- B >= 6 at
+    224 x 224; smaller inputs stay on the one-pixel-per-thread kernel, where this test compares that kernel with itself) against the
+    one-pixel-per-thread kernel, which a 4-byte-offset view of the same data is routed to: the gradient must agree bit for bit (same
+    per-pixel statements), the two values to fp64 summation order."""
     from breaching_amd.priors import launch_tv_norm
 
     rng = np.random.default_rng(12)
