@@ -92,7 +92,21 @@ __device__ __forceinline__ float4 mt_load(const float4* p) {
   }
 }
 
-template <int OP, bool HAS_A, bool NT>
+// NTS: the output list itself is larger than the Infinity Cache (BERT-base: 344 MB), so none of it can wait there for the model's
+// next forward pass; non-temporal stores keep it from evicting the operands still to be read (kernel A's backward, same policy:
+// 170.6 -> 163.2 us on that list, gm_kernels.hip BH_GM_CACHE_STREAM_ALL).
+template <bool NTS>
+__device__ __forceinline__ void mt_store(float4* p, const float4& v) {
+  if constexpr (NTS) {
+    bh_mt_v4f w;
+    w.x = v.x, w.y = v.y, w.z = v.z, w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<bh_mt_v4f*>(p));
+  } else {
+    *p = v;
+  }
+}
+
+template <int OP, bool HAS_A, bool NT, bool NTS>
 __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
                                          float* __restrict__ o, int len, float k0, float k1) {
   constexpr bool needs_b = OP != kScale, needs_c = OP == kAxpyMinus || OP == kPatch;
@@ -114,7 +128,7 @@ __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const floa
 #pragma unroll
     for (int j = 0; j < kMtIters; ++j) cv[j] = needs_c ? mt_load<NT>(c4 + tid + j * kBlock) : zero;
 #pragma unroll
-    for (int j = 0; j < kMtIters; ++j) o4[tid + j * kBlock] = mt_elem4<OP>(av[j], bv[j], cv[j], k0, k1);
+    for (int j = 0; j < kMtIters; ++j) mt_store<NTS>(o4 + tid + j * kBlock, mt_elem4<OP>(av[j], bv[j], cv[j], k0, k1));
     return;
   }
   const int n4 = len >> 2;
@@ -122,7 +136,7 @@ __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const floa
     const float4 av = HAS_A ? mt_load<NT>(a4 + i) : zero;
     const float4 bv = needs_b ? mt_load<NT>(b4 + i) : zero;
     const float4 cv = needs_c ? mt_load<NT>(c4 + i) : zero;
-    o4[i] = mt_elem4<OP>(av, bv, cv, k0, k1);
+    mt_store<NTS>(o4 + i, mt_elem4<OP>(av, bv, cv, k0, k1));
   }
   const int tail = len & 3;
   if (tid < tail) {
@@ -137,7 +151,7 @@ __device__ __forceinline__ void mt_chunk(const float* __restrict__ a, const floa
 // One workgroup per chunk.  `c_flat`: the third operand comes from a packed buffer (patch) instead of a pointer list.
 // `coef`: device pair overriding (k0, k1) when non-NULL (patch).  A NULL `a` pointer reads as zeros (scale of a missing
 // upstream gradient).
-template <int OP, bool NT>
+template <int OP, bool NT, bool NTS = false>
 __global__ __launch_bounds__(kBlock) void mt_kernel(typename MtPtrsFor<OP>::type ptrs, int tensor_base, const float* __restrict__ c_flat,
                                                     const bh_gm_chunk* __restrict__ chunks, int chunk_base, float k0,
                                                     float k1, const float* __restrict__ coef, float* __restrict__ out_flat) {
@@ -157,9 +171,9 @@ __global__ __launch_bounds__(kBlock) void mt_kernel(typename MtPtrsFor<OP>::type
   const float* __restrict__ bp = needs_b ? b + ch.tensor_off : nullptr;
   const float* __restrict__ cp = needs_c ? (OP == kAxpyMinus ? c + ch.tensor_off : c) : nullptr;
   if (a)  // uniform over the workgroup
-    mt_chunk<OP, true, NT>(a + ch.tensor_off, bp, cp, o, ch.len, k0, k1);
+    mt_chunk<OP, true, NT, NTS>(a + ch.tensor_off, bp, cp, o, ch.len, k0, k1);
   else
-    mt_chunk<OP, false, NT>(nullptr, bp, cp, o, ch.len, k0, k1);
+    mt_chunk<OP, false, NT, NTS>(nullptr, bp, cp, o, ch.len, k0, k1);
 }
 
 bool ok_ptr(const void* p, bool allow_null) {
@@ -217,6 +231,7 @@ int run_mt(int32_t n_tensors, const void* const* a, const void* const* b, const 
   // profiles/r4_mt_kernel_probe_nt.jsonl).
   constexpr int kOperands = OP == kScale ? 1 : (OP == kAxpy ? 2 : 3);
   const bool stream_loads = n_chunks * (int64_t)BH_GM_CHUNK * 4 * (kOperands + 1) > (int64_t)BH_GM_CACHE_AUTO_BYTES;
+  const bool stream_stores = n_chunks * (int64_t)BH_GM_CHUNK * 4 > (int64_t)BH_GM_CACHE_AUTO_BYTES;  // the output alone does not fit
   for (int g = 0; g < launches; ++g) {
     const int first = g * P::kGroups, last = (first + P::kGroups) < base_groups ? (first + P::kGroups) : base_groups;
     const int begin = group_chunk_begin[first], n = group_chunk_begin[last] - begin;
@@ -224,7 +239,10 @@ int run_mt(int32_t n_tensors, const void* const* a, const void* const* b, const 
     P ptrs;
     fill(ptrs, a, b, c, n_tensors, g, a_nullable);
     const int tensor_base = g * P::kGroups * BH_MT_MAX_PTRS;
-    if (stream_loads)
+    if (stream_stores)
+      hipLaunchKernelGGL((mt_kernel<OP, true, true>), dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, c_flat, chunks_dev, begin, k0, k1,
+                         coef, out_flat);
+    else if (stream_loads)
       hipLaunchKernelGGL((mt_kernel<OP, true>), dim3(n), dim3(kBlock), 0, st, ptrs, tensor_base, c_flat, chunks_dev, begin, k0, k1, coef,
                          out_flat);
     else

@@ -337,7 +337,7 @@ int bh_mt_group_bounds(int32_t n_tensors, const bh_gm_chunk* chunks_host, int64_
  * sub round separately, exactly like torch's `param - lr * grad` and `p_local - p_server`.  Host arrays of device
  * pointers, each tensor contiguous fp32 and 16-byte aligned.  Cache policy (all bh_mt_* calls): operands are read with plain
  * loads while operands + output fit BH_GM_CACHE_AUTO_BYTES (the Infinity Cache), with non-temporal loads beyond; the
- * output is always written with plain stores (the model's next forward pass reads it).  Same values either way.
+ * output is written with plain stores (the model's next forward pass reads it) unless it alone exceeds that size.  Same values.
  * reference: objectives.py:64-69 (`params = [param - lr * grad ...]`, `gradient = [p_local - p_server ...]`). */
 int bh_mt_axpy(int32_t n_tensors, const void* const* a_ptrs, const void* const* b_ptrs, const void* const* c_ptrs,
                float alpha, const bh_gm_chunk* chunks_dev, int64_t n_chunks, const int32_t* group_chunk_begin,

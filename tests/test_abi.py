@@ -386,9 +386,10 @@ def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
             assert row["ld128"] == 2 * operands and row["st128"] == 4 and row["ld32"] <= 4 and row["st32"] == 0, (name, row)
         if name.startswith("tv_norm_vec4_kernel"):  # kernel C's: centre / south / north rows of three planes as 16-byte loads
             assert row["ld128"] >= 8 and row["st128"] >= 3 and row["st32"] == 0, (name, row)
-        m = re.match(r"(gm_fwd_kernel|mt_kernel)<(\d+), (true|false)>", name)
-        if m:  # kernel A forward and the multi-tensor kernels: the template flag puts `nt` on every 16-byte load, or on none
-            assert row["ld_nt"] == (row["ld128"] if m.group(3) == "true" else 0) and row["st_nt"] == 0, (name, row)
+        m = re.match(r"(gm_fwd_kernel|mt_kernel)<(\d+), (true|false)(, (true|false))?>", name)
+        if m:  # kernel A forward and the multi-tensor kernels: the template flags put `nt` on every 16-byte load / store, or on none
+            assert row["ld_nt"] == (row["ld128"] if m.group(3) == "true" else 0), (name, row)
+            assert (row["st_nt"] > 0) == (m.group(5) == "true"), (name, row)
         m = re.match(r"gm_fwd_kernel<(\d+), (true|false)>", name)
         if m:
             assert row["ld_nt"] == (row["ld128"] if m.group(2) == "true" else 0), (name, row)
