@@ -53,7 +53,7 @@ def pmc_traffic_bytes(kernel, sources=None):
     """HBM bytes per launch from the committed PMC passes (profiles/r*_pmc_{fetch,write}_pmc_summary.csv, the newest of
     each): FETCH_SIZE (KB) x 2 -- the gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md section HBM -- plus
     WRITE_SIZE (KB).  bench.py cannot collect counters itself: separate `rocprofv3 --pmc` passes do, one counter per pass,
-    over scripts/pmc_target.py at this workload's list size (round 3: scripts/r3_call6.sh; under the full attack loop
+    over scripts/pmc_target.py at this workload's list size (scripts/gpu_call.sh pmc_resnet18; under the full attack loop
     rocprofv3's counter collection segfaults inside torch's convolution on this image).  None when the profiles are absent.
     `sources` (a list) receives the file names used."""
     import csv
@@ -394,7 +394,7 @@ def main():
         # waits for the slowest)
         from breaching_amd.workers import isolate_miopen_user_db
 
-        isolate_miopen_user_db(rank)
+        miopen_dir = isolate_miopen_user_db(rank)
     assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     oversubscribed = world > torch.cuda.device_count()
@@ -419,6 +419,17 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=limit)
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
+    # Staged start (N > 1): rank 0 builds its trial and runs its warm-up first -- on a fresh box that is where MIOpen searches a solver
+    # for every convolution configuration of the three autograd orders -- while the other ranks wait in front of their first
+    # convolution; they then start from a COPY of rank 0's find-db: no eight concurrent searches (on one CPU, one sqlite lock) inside
+    # the warm-up of the scaling run, and every rank runs the solvers rank 0 chose (equal speed, comparable results).
+    miopen_seeded = None
+    if world > 1 and rank > 0:
+        dist.barrier()
+        from breaching_amd.workers import default_miopen_user_db, seed_miopen_user_db
+
+        if miopen_dir is not None and os.path.basename(miopen_dir).startswith("breach_hip_rank"):
+            miopen_seeded = seed_miopen_user_db(os.path.join(default_miopen_user_db(), "breach_hip_rank0"), miopen_dir)
 
     # ---- workload --------------------------------------------------------------------------------------------------
     torch.manual_seed(0)
@@ -487,6 +498,9 @@ def main():
     warmup_steps = args.warmup if args.no_graph else max(args.warmup, GRAPH_WARMUP_ITERATIONS + 2)
     for _ in range(warmup_steps):
         step_all()
+    if world > 1 and rank == 0:
+        torch.cuda.synchronize(device)
+        dist.barrier()  # releases the other ranks of the staged start (above)
     plan = attacker.objective._plan
     timed_with_events = plan is not None and not args.no_kernel_timing and run.graph is None
     if timed_with_events:
@@ -682,6 +696,7 @@ def main():
             "rccl_dry_run": rccl_dry_run,
             "collective_backend": backend if world > 1 else None,
             "oversubscribed": bool(oversubscribed),
+            "staged_start": None if world == 1 else "rank 0 warms up first; ranks > 0 start from a copy of its MIOpen find-db",
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -96,19 +96,50 @@ def to_cpu(obj):
     return obj
 
 
-def isolate_miopen_user_db(rank):
-    """Give this rank its own MIOpen user database directory unless the user chose one.  On a fresh box every process runs
-    MIOpen's solver search for each convolution configuration on first use and records the result in the user find-db; eight
-    first processes sharing one sqlite file serialise on its lock and time their candidate solvers against each other
-    (profiles/r3_miopen_selection.txt: the search doubles the dispatches of the first iterations).  Must run before the
-    process's first convolution."""
+def default_miopen_user_db():
+    """Where MIOpen keeps the user find-db when nobody says otherwise."""
+    return os.path.join(os.path.expanduser("~"), ".config", "miopen")
+
+
+def seed_miopen_user_db(source, target):
+    """Copy the files of one MIOpen user database directory into another (top level only: the per-rank directories of this
+    module live INSIDE the default one and must not be copied into each other).  Returns the number of files copied."""
+    import shutil
+
+    copied = 0
+    try:
+        for name in os.listdir(source):
+            src = os.path.join(source, name)
+            if os.path.isfile(src):
+                shutil.copy2(src, os.path.join(target, name))
+                copied += 1
+    except OSError:
+        pass
+    return copied
+
+
+def isolate_miopen_user_db(rank, seed_from=None):
+    """Give this rank its own MIOpen user database directory unless the user chose one (MIOPEN_USER_DB_PATH set) or switched
+    the isolation off (BREACH_HIP_MIOPEN_ISOLATE=0).  On a fresh box every process runs MIOpen's solver search for each
+    convolution configuration on first use and records the result in the user find-db; eight first processes sharing one sqlite
+    file serialise on its lock and time their candidate solvers against each other (profiles/r3_miopen_selection.txt: the
+    search doubles the dispatches of the first iterations).  Must run before the process's first convolution.
+
+    The directory is ~/.config/miopen/breach_hip_rank<r>.  It starts as a COPY of `seed_from` (default: the user's existing
+    find-db, ~/.config/miopen) when that holds anything, so an already tuned database is not thrown away and ranks that start from
+    the same database pick the same solvers; results of later searches stay in the rank's own directory."""
     if "MIOPEN_USER_DB_PATH" in os.environ:
         return os.environ["MIOPEN_USER_DB_PATH"]
-    path = os.path.join(os.path.expanduser("~"), ".config", "miopen", f"breach_hip_rank{int(rank)}")
+    if os.environ.get("BREACH_HIP_MIOPEN_ISOLATE", "1").strip().lower() in ("0", "false", "off", "no"):
+        return None
+    path = os.path.join(default_miopen_user_db(), f"breach_hip_rank{int(rank)}")
     try:
         os.makedirs(path, exist_ok=True)
     except OSError:
         return None
+    source = seed_from if seed_from is not None else default_miopen_user_db()
+    if os.path.isdir(source) and os.path.abspath(source) != os.path.abspath(path) and not os.listdir(path):
+        seed_miopen_user_db(source, path)
     os.environ["MIOPEN_USER_DB_PATH"] = path
     return path
 

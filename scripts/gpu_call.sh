@@ -63,6 +63,7 @@ pmc_resnet18() { pmc resnet18; }
 pmc_mt()       { pmc mt_resnet50; pmc mt_bert; }
 configs()  { timeout 1500 python scripts/config_runs.py > $OUT/${TAG}_config_runs_same_process.log 2>&1; tail -12 $OUT/${TAG}_config_runs_same_process.log | cut -c1-400; }
 control()  { timeout 900 python tests/control_same_gpu_torch.py --out $OUT/${TAG}_control_same_gpu_torch.json > $OUT/${TAG}_control_same_gpu_torch.log 2>&1; tail -14 $OUT/${TAG}_control_same_gpu_torch.log | cut -c1-260; }
+hip64()    { timeout 600 python tests/control_same_gpu_torch.py --hip-only --starts 64 --out $OUT/${TAG}_hip_64starts_1000its.json > $OUT/${TAG}_hip_64starts_1000its.log 2>&1; tail -10 $OUT/${TAG}_hip_64starts_1000its.log | cut -c1-200; }
 stepprior_trace() {
   prof 200 step_prior_probe "" python $GRAFT_REPO_ROOT/scripts/step_prior_probe.py --launches 20
   BREACH_HIP_LIB=$PREV prof 200 step_prior_probe_prev "" python $GRAFT_REPO_ROOT/scripts/step_prior_probe.py --launches 20

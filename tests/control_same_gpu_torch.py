@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--iterations", type=int, default=1000)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "control_same_gpu_torch.json"))
     ap.add_argument("--worker", nargs=2, default=None)
+    ap.add_argument("--hip-only", action="store_true",
+                    help="only the HIP runs (cheap: 64 starts x 1000 iterations take about two minutes), for a larger sample of the HIP "
+                         "distribution against reference runs generated on CPU (oracle/make_golden.py --long-worker IDX OUT)")
+    ap.add_argument("--processes", type=int, default=3, help="torch-on-GPU worker processes at a time (eight at once ran at 8 it/s each)")
     args = ap.parse_args()
     gold = np.load(os.path.join(ROOT, "tests", "golden", "attack_resnet18_long.npz"))
     seed = int(gold["twin_seed"])
@@ -106,13 +110,24 @@ def main():
         return
     assert args.iterations == int(gold["iterations"]), "the stored CPU reference runs are 1000 iterations long"
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    if args.hip_only:
+        hip, hip_wall = hip_runs(args.starts, args.iterations, seed)
+        name, cols = table("hip", hip)
+        report = dict(starts=args.starts, iterations=args.iterations, hip_wall_s=round(hip_wall, 1),
+                      hip={k: dict(mean=float(v.mean()), sd=float(v.std(ddof=1)), n=int(len(v)), values=[round(float(x), 6) for x in v]) for k, v in cols.items()})
+        for k, v in cols.items():
+            print(f"{k:10s} hip {v.mean():.6f} +- {v.std(ddof=1):.6f} (n = {len(v)}, standard error {v.std(ddof=1) / np.sqrt(len(v)):.6f})", flush=True)
+        with open(args.out, "w") as f:
+            json.dump(report, f, indent=1)
+        return
     t0 = time.perf_counter()
-    procs = []
-    for idx in range(args.starts):
-        path = f"{args.out}.worker{idx}.json"
-        procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(idx), path, "--iterations", str(args.iterations)]), path))
-    torch_runs = []
-    for proc, path in procs:
+    torch_runs, pending, running = [], list(range(args.starts)), []
+    while pending or running:
+        while pending and len(running) < args.processes:
+            idx = pending.pop(0)
+            path = f"{args.out}.worker{idx}.json"
+            running.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(idx), path, "--iterations", str(args.iterations)]), path))
+        proc, path = running.pop(0)
         proc.wait()
         if proc.returncode == 0:
             with open(path) as f:

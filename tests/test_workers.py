@@ -139,16 +139,36 @@ def test_requested_devices_parsing(monkeypatch):
 
 def test_each_rank_gets_its_own_miopen_user_db(monkeypatch, tmp_path):
     """Eight first processes on a fresh box must not share one MIOpen find-db file (lock contention, solver timings taken
-    against each other): every rank points MIOPEN_USER_DB_PATH at its own directory unless the user already chose one."""
+    against each other): every rank points MIOPEN_USER_DB_PATH at its own directory unless the user already chose one or switched
+    the isolation off; the directory starts as a copy of the user's existing find-db (an already tuned database is kept, ranks
+    that start from the same database pick the same solvers), and bench.py's staged start copies rank 0's into the others."""
+    import os
+
     from breaching_amd import workers
 
     monkeypatch.setenv("HOME", str(tmp_path))
     monkeypatch.delenv("MIOPEN_USER_DB_PATH", raising=False)
+    monkeypatch.delenv("BREACH_HIP_MIOPEN_ISOLATE", raising=False)
+    tuned = tmp_path / ".config" / "miopen"
+    tuned.mkdir(parents=True)
+    (tuned / "gfx950_256.HIP.3_5_1.ufdb.txt").write_text("tuned on this box\n")
     first = workers.isolate_miopen_user_db(3)
-    assert first.endswith("breach_hip_rank3") and first.startswith(str(tmp_path)) and __import__("os").path.isdir(first)
+    assert first.endswith("breach_hip_rank3") and first.startswith(str(tmp_path)) and os.path.isdir(first)
+    assert os.listdir(first) == ["gfx950_256.HIP.3_5_1.ufdb.txt"]  # seeded from the existing database
     assert workers.isolate_miopen_user_db(5) == first  # already set in this process (by the call above): left alone
     monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
     assert workers.isolate_miopen_user_db(1) == "/somewhere/else"
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    monkeypatch.setenv("BREACH_HIP_MIOPEN_ISOLATE", "0")
+    assert workers.isolate_miopen_user_db(2) is None and "MIOPEN_USER_DB_PATH" not in os.environ  # opt-out: the shared default database
+    monkeypatch.delenv("BREACH_HIP_MIOPEN_ISOLATE")
+    # the staged start: rank 0's results copied over whatever the other rank's directory holds
+    zero = workers.isolate_miopen_user_db(0)
+    monkeypatch.delenv("MIOPEN_USER_DB_PATH")
+    with open(os.path.join(zero, "found_by_rank0.udb"), "w") as f:
+        f.write("x")
+    other = workers.isolate_miopen_user_db(6)
+    assert workers.seed_miopen_user_db(zero, other) == 2 and sorted(os.listdir(other)) == ["found_by_rank0.udb", "gfx950_256.HIP.3_5_1.ufdb.txt"]
 
 
 def test_eight_ranks_share_32_restarts_like_an_eight_gpu_node():
