@@ -17,7 +17,9 @@
 //   backward       gz = gy * [y > 0] ;  gx = gz * s_c ;  gr = gz ;  gw_c, gb_c from gz
 //   backward^2     d_gy = [y > 0] * (ggx * s_c + ggr + ggw_c * (inv_c * x - mi_c) + ggb_c) ;  d_x = ggw_c * inv_c * gz ;
 //                  d_w_c = inv_c * sum(ggx * gz)
-// (ReLU's second derivative vanishes almost everywhere: the mask is a constant of all three orders, read back from y.)  On
+// (ReLU's second derivative vanishes almost everywhere: the mask is a constant of all three orders, read back from y.  The mask is
+// !(y <= 0), not y > 0: a NaN pre-activation stays NaN in the forward, as in torch, and must then pass its gradient like torch's
+// threshold_backward does, instead of being zeroed.)  On
 // ResNet-18 that removes ~110 of the ~717 launches of an attack iteration: clamp_min, threshold_backward in both passes, the
 // derivative of threshold_backward and its zero fill, and the residual add (profiles/r4_op_attribution.txt).
 // The backward can also carry the DeepInversion prior's term of this BatchNorm input: gx += gout * (A_c + B_c * x).
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
             const float4 q = qv[k];
             if (ymask) {
               const float4 m = mv[k];
-              g = make_float4(m.x > 0.f ? g.x : 0.f, m.y > 0.f ? g.y : 0.f, m.z > 0.f ? g.z : 0.f, m.w > 0.f ? g.w : 0.f);
+              g = make_float4(m.x <= 0.f ? 0.f : g.x, m.y <= 0.f ? 0.f : g.y, m.z <= 0.f ? 0.f : g.z, m.w <= 0.f ? 0.f : g.w);  // !(y <= 0): see the header
             }
             if (gres) gres4[at[k]] = g;
             if (gx) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_kernel(const float* __rest
         const size_t at = slab_offset(u, B, unit, cstride, cbase);
         float g = gy[at];
         const float q = x[at];
-        if (ymask && !(ymask[at] > 0.f)) g = 0.f;
+        if (ymask && ymask[at] <= 0.f) g = 0.f;
         if (gres) gres[at] = g;
         if (gx) gx[at] = (tap_coef ? g * s + fmaf(tb, q, ta) : g * s) + (add_in ? add_in[at] : 0.f);
         a0 += g;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
             const float4 q = qv[k];
             float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
             if (ymask) {
-              m = make_float4(yv[k].x > 0.f ? 1.f : 0.f, yv[k].y > 0.f ? 1.f : 0.f, yv[k].z > 0.f ? 1.f : 0.f, yv[k].w > 0.f ? 1.f : 0.f);
+              m = make_float4(yv[k].x <= 0.f ? 0.f : 1.f, yv[k].y <= 0.f ? 0.f : 1.f, yv[k].z <= 0.f ? 0.f : 1.f, yv[k].w <= 0.f ? 0.f : 1.f);
               g = make_float4(g.x * m.x, g.y * m.y, g.z * m.z, g.w * m.w);  // gz
             }
             if (d_gy) {
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(kBlock) void bn_eval_bwd_bwd_kernel(const float* __
         const size_t at = slab_offset(u, B, unit, cstride, cbase);
         float g = gy[at];
         const float q = ggx ? ggx[at] : 0.f;
-        const bool on = ymask == nullptr || ymask[at] > 0.f;
+        const bool on = ymask == nullptr || !(ymask[at] <= 0.f);
         if (!on) g = 0.f;  // gz
         if (d_gy) d_gy[at] = on ? fmaf(q, s, fmaf(kwi, x[at], shift)) + (ggr ? ggr[at] : 0.f) : 0.f;
         if (d_x) d_x[at] = kwi * g;

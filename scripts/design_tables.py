@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROFILES = os.path.join(ROOT, "profiles")
-BEGIN = "<!-- BEGIN GENERATED: round-4 tables (scripts/design_tables.py) -->"
+BEGIN = "<!-- BEGIN GENERATED: round-5 tables (scripts/design_tables.py) -->"
 END = "<!-- END GENERATED -->"
 PEAK = 8000.0  # GB/s, MI355X_MICROARCH.md
 
@@ -81,84 +81,196 @@ def fmt(v, nd=1):
     return "n/a" if v is None else f"{v:.{nd}f}"
 
 
+N_LIST = {"resnet18": 11_689_512, "resnet50": 25_557_032, "bert_base": 86_073_402}
+
+
+def _by_grid(name):
+    """[(kernel short name with template arguments, workgroups, calls, avg us, median us)] from a `_kernel_by_grid.csv`."""
+    path = os.path.join(PROFILES, name)
+    out = []
+    if not os.path.exists(path):
+        return out
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            m = re.match(r"([A-Za-z_0-9]+(?:<[^>]*>)?)", row["kernel"])
+            out.append((m.group(1) if m else row["kernel"][:40], int(row["workgroups"]), int(row["calls"]), float(row["avg_us"]), float(row["median_us"])))
+    return out
+
+
+def _frac(nbytes, us):
+    return nbytes / us / 1e3 / PEAK
+
+
+def _pmc_ratio(fetch_file, write_file, kernel, algorithmic, dispatches_per_call=1):
+    f, w = _pmc(fetch_file, kernel), _pmc(write_file, kernel)
+    if f is None or w is None:
+        return None
+    traffic = (2.0 * f + w) * 1024.0 * dispatches_per_call  # FETCH_SIZE counts half of wide coalesced reads on gfx950; values in KiB
+    return traffic, traffic / algorithmic
+
+
 def build():
-    L = [BEGIN, "", "*(generated from the files named in the right-hand column; do not edit by hand)*", ""]
-    b = _json_line("r4_bench_n1.json")
-    b4 = _json_line("r4_bench_n1_4trials_in_flight.json")
-    b2 = _json_line("r4_bench_2ranks_one_gpu.json")
-    L += ["| quantity | value | file |", "|---|---|---|"]
+    L = [BEGIN, "", "*(generated from the files named next to each figure; do not edit by hand)*", ""]
+    b = _json_line("r5_bench_driver_style.json")
+    L += ["**The driver-style line** (`python bench.py --gpus 1 --steps 20 --warmup 5`, `r5_bench_driver_style.json`):", "",
+          "| quantity | value |", "|---|---|"]
     if b:
         r, k = b["roofline"], b["kernels"]
-        L.append(f"| attack iterations / s, 1 GPU, one trial, {b['launch_mode']} | **{b['value']:.1f}** ({b['ms_per_step']:.3f} ms / iteration; eager launches: {fmt(b.get('eager_ms_per_step'), 2)} ms) | `r4_bench_n1.json` |")
-        L.append(f"| kernel A forward, HIP ext-launch events, ResNet-18 list ({r['algorithmic_bytes'] / 1e6:.1f} MB, Infinity-Cache resident) | {r['avg_launch_us']:.2f} us -> {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of 8 TB/s; stage with finalize {r['stage_us']:.2f} us = {r['stage_frac']:.3f}; device span inside graph replay {fmt(r.get('timed_region_span_us'), 2)} us | same |")
-        L.append(f"| kernel A backward, same method ({k['bwd']['algorithmic_bytes'] / 1e6:.1f} MB) | {k['bwd']['avg_us']:.2f} us -> {k['bwd']['achieved_GBs']:.0f} GB/s = **{k['bwd']['frac_of_hbm_peak']:.3f}** | same |")
-        L.append(f"| PMC traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE), forward / backward | {r['traffic'] / 1e6:.2f} MB vs {r['algorithmic_bytes'] / 1e6:.2f} MB ({r['traffic'] / r['algorithmic_bytes']:.3f}) / {k['bwd']['traffic'] / 1e6:.2f} MB vs {k['bwd']['algorithmic_bytes'] / 1e6:.2f} MB ({k['bwd']['traffic'] / k['bwd']['algorithmic_bytes']:.3f}) | `{', '.join(sorted(set(re.findall(r'r[0-9]_pmc_[a-z]+_pmc_summary.csv', r.get('traffic_source', '')))))}` |")
+        L.append(f"| attack iterations / s, 1 GPU, one trial, {b['launch_mode']} | **{b['value']:.1f}** ({b['ms_per_step']:.3f} ms / iteration; eager launches {fmt(b.get('eager_ms_per_step'), 2)} ms) |")
+        g = b.get("gpu_torch_baseline") or {}
+        c = b.get("cpu_baseline") or {}
+        if g.get("value"):
+            L.append(f"| the same attack with PyTorch-ROCm ops on the same GPU (`gpu_torch_baseline`: oracle/restate.py on cuda) | {g['value']:.1f} it/s -> the HIP path is **{b['value'] / g['value']:.1f}x** |")
+        if c:
+            anchor = c.get("anchor") or {}
+            L.append(f"| CPU baseline in the same run ({c['kind']}; {c['cores']} of {c['host_cpu_count']} logical cores) | {c['value']:.2f} it/s" +
+                     (f"; port / unmodified reference on equal threads = {anchor.get('port_over_reference')} (`{anchor.get('file')}`)" if anchor else "") + " |")
+        L.append(f"| kernel A forward, dispatch start/stop events, ResNet-18 list ({r['algorithmic_bytes'] / 1e6:.1f} MB, Infinity-Cache resident) | {r['avg_launch_us']:.2f} us -> {r['achieved']:.0f} GB/s = **{r['frac']:.3f}** of 8 TB/s; stage with finalize {r['stage_us']:.2f} us = {r['stage_frac']:.3f}; device span inside graph replay {fmt(r.get('timed_region_span_us'), 2)} us |")
+        ce = r.get("ceiling") or {}
+        if ce.get("us"):
+            L.append(f"| `roofline.ceiling`: bare read of the same bytes with kernel A's grid and loads, behind a writer, same events, same run | {ce['us']:.2f} us = {ce['GBs']:.0f} GB/s ({ce['behind_writer']['frac_of_hbm_peak']:.3f} of 8 TB/s; warm {ce['warm']['median_us']:.2f} us) -> kernel A forward at **{r.get('frac_of_ceiling', 0):.2f} of the measured ceiling** |")
+        L.append(f"| kernel A backward ({k['bwd']['algorithmic_bytes'] / 1e6:.1f} MB) | {k['bwd']['avg_us']:.2f} us -> {k['bwd']['achieved_GBs']:.0f} GB/s = **{k['bwd']['frac_of_hbm_peak']:.3f}** |")
+        if r.get("traffic") and k["bwd"].get("traffic"):
+            L.append(f"| PMC traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE; committed passes at HEAD), forward / backward | {r['traffic'] / 1e6:.2f} MB vs {r['algorithmic_bytes'] / 1e6:.2f} MB (**{r['traffic'] / r['algorithmic_bytes']:.3f}**) / {k['bwd']['traffic'] / 1e6:.2f} vs {k['bwd']['algorithmic_bytes'] / 1e6:.2f} MB (**{k['bwd']['traffic'] / k['bwd']['algorithmic_bytes']:.3f}**) |")
         h = r.get("hbm_resident") or {}
         for kind in ("cosine-similarity", "tag-euclidean"):
             if kind in h:
                 e = h[kind]
-                L.append(f"| **HBM-resident** list (BERT-base, {h['elements'] / 1e6:.2f} M elements, {2 * h['elements'] * 4 / 1e6:.1f} MB per forward launch), {kind}, in the SAME run | fwd {e['fwd_us']:.1f} us = **{e['frac']:.3f}** (stage {e['stage_frac']:.3f}" + (f"; not behind a writer: {e['fwd_not_behind_a_writer_us']:.1f} us = {e['frac_not_behind_a_writer']:.3f}" if "frac_not_behind_a_writer" in e else "") + f"); bwd {e['bwd_us']:.1f} us = **{e['bwd_frac']:.3f}** | same (`roofline.hbm_resident`) |")
-        c = b.get("cpu_baseline")
-        if c:
-            anchor = c.get("anchor") or {}
-            L.append(f"| CPU baseline in the same run ({c['kind']}; {c['cores']} of {c['host_cpu_count']} logical cores) | {c['value']:.2f} it/s" +
-                     (f"; port / unmodified reference on equal threads = {anchor.get('port_over_reference')} (`{anchor.get('file')}`)" if anchor else "") + " | same |")
-    if b4:
-        L.append(f"| four restarts in flight on one GPU (streams on four different hardware pipes) | **{b4['value']:.1f}** it/s ({b4['ms_per_step']:.2f} ms per round of four) | `r4_bench_n1_4trials_in_flight.json` |")
-    if b2:
-        L.append(f"| two ranks sharing the one GPU (`bench.py --gpus 2`, {b2.get('collective_backend')}, oversubscribed: functional check) | {b2['value']:.1f} it/s; per-rank ms/step {b2.get('per_rank_ms_per_step')}, skew {b2.get('rank_skew')} | `r4_bench_2ranks_one_gpu.json` |")
-    sweep = _json_line("r4_cpu_thread_sweep.json")
-    if sweep:
-        L.append("| CPU thread sweep on the GPU box's host (port, it/s by threads) | " + ", ".join(f"{t}: {v}" for t, v in sweep["iterations_per_s"].items()) + f" -> {sweep['best_threads']} threads | `r4_cpu_thread_sweep.json` |")
+                sp = e.get("fwd_us_min_median_max") or {}
+                L.append(f"| **HBM-resident** list (BERT-base, {2 * h['elements'] * 4 / 1e6:.1f} MB per forward launch), {kind}, same run | fwd {e['fwd_us']:.1f} us = **{e['frac']:.3f}**" +
+                         (f" (min / median / max of 30: {sp.get('min')} / {sp.get('median')} / {sp.get('max')} us)" if sp else "") +
+                         f", stage {e['stage_frac']:.3f}; bwd {e['bwd_us']:.1f} us = **{e['bwd_frac']:.3f}** |")
+        pa = b.get("parity") or {}
+        if pa.get("iterate"):
+            L.append(f"| `parity`: the timed configuration at the reference's iterate k = {pa['iterate']} of its 24 000-iteration CPU run | loss {pa['loss_hip']:.6f} vs {pa['loss_reference']:.6f} (rel {pa['loss_rel_err']:.1e}, tolerance {pa['loss_tolerance']:.1e} = 10x the reference's own kink sensitivity there); sign(d total/dx) equal on **{pa['sign_agreement']:.4f}** of the pixels (reference vs itself 16 ulp away: {pa['reference_twin_agreement']:.4f}), |g|-weighted {pa['weighted_sign_agreement']:.5f} ({pa['reference_twin_weighted_agreement']:.4f}) |")
+    for name, label in (("r5_bench_n1.json", "default flags (200 steps)"), ("r5_bench_n1_4trials_in_flight.json", "four restarts in flight on one GPU")):
+        x = _json_line(name)
+        if x:
+            L.append(f"| {label} (`{name}`) | **{x['value']:.1f}** it/s ({x['ms_per_step']:.3f} ms per step) |")
+    b8 = _json_line("r5_bench_8ranks_one_gpu.json")
+    if b8:
+        L.append(f"| rehearsal of the 8-rank launch on ONE GPU (`torch.distributed.run --nproc-per-node 8`, {b8.get('collective_backend')}, oversubscribed; `r5_bench_8ranks_one_gpu.json`) | {b8['value']:.1f} it/s aggregate, every rank `{b8['launch_mode']}`, per-rank ms/step {b8.get('per_rank_ms_per_step')}, skew {b8.get('rank_skew')}; staged start: {b8.get('staged_start')} |")
     L.append("")
-    # --- in-loop kernel durations
-    ks = _kernel_summary("r4_bench_kernel_summary.txt")
+
+    # --- kernel A in the loop at the three BASELINE sizes
+    rows = []
+    for label, fname, lst, fwd_key, bwd_key, pmc_tag in (
+            ("ResNet-18 (configs[1], bench command)", "r5_bench_kernel_summary.txt", "resnet18", "gm_fwd_kernel<0, false>", "gm_bwd_kernel<0, false, false>", "resnet18"),
+            ("ResNet-50 B = 8 see-through (configs[2])", "r5_config3_resnet50_seethrough_kernel_summary.txt", "resnet50", "gm_fwd_kernel<4, true>", "gm_bwd_kernel<4, false, false>", None),
+            ("BERT-base TAG (configs[4])", "r5_config5_bert_tag_kernel_summary.txt", "bert_base", "gm_fwd_kernel<6, true>", "gm_bwd_kernel<6, true, true>", "bert")):
+        ks = _kernel_summary(fname)
+        if not ks or fwd_key not in ks:
+            continue
+        n = N_LIST[lst]
+        f_us, b_us = ks[fwd_key][1], ks[bwd_key][1]
+        fin = ks.get("gm_finalize_kernel", (0, 0.0))[1]
+        cell = f"| {label} | {2 * n * 4 / 1e6:.1f} | `{fwd_key}` {f_us:.2f} us = **{_frac(2 * n * 4, f_us):.2f}** (stage + {fin:.2f} us = {_frac(2 * n * 4, f_us + fin):.2f}) | `{bwd_key}` {b_us:.2f} us = **{_frac(3 * n * 4, b_us):.2f}** |"
+        if pmc_tag:
+            pf = _pmc_ratio(f"r5_pmc_fetch_{pmc_tag}_pmc_summary.csv", f"r5_pmc_write_{pmc_tag}_pmc_summary.csv", "gm_fwd_kernel", 2 * n * 4)
+            pb = _pmc_ratio(f"r5_pmc_fetch_{pmc_tag}_pmc_summary.csv", f"r5_pmc_write_{pmc_tag}_pmc_summary.csv", "gm_bwd_kernel", 3 * n * 4)
+            cell += f" {fmt(pf[1], 3) if pf else 'n/a'} / {fmt(pb[1], 3) if pb else 'n/a'} |"
+        else:
+            cell += " (round 3: 1.00 / 1.00) |"
+        rows.append(cell + f" `{fname}` |")
+    if rows:
+        L += ["**Kernel A inside the attack loop** (rocprofv3 kernel trace of the whole run, average dispatch duration; fraction of the 8 TB/s peak on ALGORITHMIC bytes 2 N 4 / 3 N 4; PMC = (2 x FETCH_SIZE + WRITE_SIZE) / algorithmic bytes from separate `--pmc` passes over `scripts/pmc_target.py` with the AUTO cache policy, i.e. the non-temporal instantiations at BERT size):", "",
+              "| list | forward MB | forward | backward | PMC traffic ratio fwd / bwd | file |", "|---|---|---|---|---|---|"] + rows + [""]
+
+    # --- read ceiling
+    probe = _jsonl("r5_read_ceiling_probe.jsonl")
+    rows = []
+    for lst in ("resnet18", "resnet50", "bert_base"):
+        ka = next((p for p in probe if p.get("list") == lst and p.get("kernel", "").startswith("kernel A forward (cosine), model list")), None)
+        one = next((p for p in probe if p.get("list") == lst and "one tensor" in p.get("kernel", "")), None)
+        dg = next((p for p in probe if p.get("list") == lst and p.get("kernel", "").startswith("diag_read, dispatch")), None)
+        if ka and dg:
+            best_w = min(v for v in (dg.get("behind_writer_us"), dg.get("nt_behind_writer_us")) if v)
+            best = min(v for v in (dg.get("warm_us"), dg.get("nt_warm_us")) if v)
+            rows.append(f"| {lst} ({ka['bytes'] / 1e6:.1f} MB) | {dg['warm_us']} / {dg['nt_warm_us']} | {dg['behind_writer_us']} / {dg['nt_behind_writer_us']} | {ka['warm_us']} | {ka['behind_writer_us']} ({one['behind_writer_us'] if one else 'n/a'}) | **{best_w / ka['behind_writer_us']:.2f}** ({best / ka['warm_us']:.2f}) |")
+    if rows:
+        L += ["**The ceiling kernel A's forward is priced against** (`r5_read_ceiling_probe.jsonl`; `diag_read` = kernel A's persistent grid of 512 workgroups and eight staged 16-byte loads per lane over two buffers, two multiply-adds per element, outside the library; all columns: dispatch start/stop events, median of 30, us):", "",
+              "| list | bare read warm: plain / non-temporal loads | bare read behind a writer: plain / nt | kernel A forward warm | kernel A forward behind a writer (same bytes as ONE tensor: full chunks only) | best bare read / kernel A, behind a writer (warm) |", "|---|---|---|---|---|---|"] + rows + [""]
+
+    # --- multi-tensor kernels
+    rows = []
+    sa = _by_grid("r5_mt_kernel_probe_kernel_by_grid.csv")
+    wg = {2893: "resnet18", 6334: "resnet50", 21110: "bert_base"}
+    ops = {"mt_kernel<0": ("a + alpha b", 3), "mt_kernel<2": ("alpha a", 2)}
+    for kname, wgs, calls, avg, med in sa:
+        for pref, (label, words) in ops.items():
+            if kname.startswith(pref) and wgs in wg:
+                n = N_LIST[wg[wgs]]
+                rows.append(f"| {label} | {wg[wgs]} | one launch, {wgs} workgroups | {avg:.2f} | **{_frac(words * n * 4, avg):.2f}** | stand-alone, back to back (`r5_mt_kernel_probe_kernel_by_grid.csv`) |")
+    for fname, lst in (("r5_fedavg_resnet18_kernel_by_grid.csv", "resnet18"), ("r5_fedavg_resnet50_kernel_by_grid.csv", "resnet50")):
+        g = _by_grid(fname)
+        n = N_LIST[lst]
+        for pref, (label, words) in ops.items():
+            hit = [x for x in g if x[0].startswith(pref)]
+            if hit:
+                us = sum(x[3] for x in hit)
+                rows.append(f"| {label} | {lst} | {len(hit)} launch(es) | {us:.2f} | **{_frac(words * n * 4, us):.2f}** | inside a FedAvg attack iteration (`{fname}`) |")
+        minus = [x for x in g if x[0].startswith("mt_kernel<1")]
+        if minus:
+            us = sum(x[3] for x in minus)
+            rows.append(f"| (a + alpha b) - c | {lst} | {len(minus)} launch(es) (three pointer lists: 112 tensors per launch) | {us:.2f} | **{_frac(4 * n * 4, us):.2f}** | inside a FedAvg attack iteration (`{fname}`) |")
+        bw = [x for x in g if x[0].startswith("gm_bwd_kernel")]
+        if bw:
+            rows.append(f"| kernel A backward, for comparison (3 N 4) | {lst} | 1 | {bw[0][3]:.2f} | {_frac(3 * n * 4, bw[0][3]):.2f} | same trace |")
+    if rows:
+        L += ["**Multi-tensor kernels (SURVEY section 8 f2 / f3)** -- rocprofv3 dispatch durations, fraction of 8 TB/s on algorithmic bytes (3 N 4 / 2 N 4 / 4 N 4):", "",
+              "| form | list | launches per call | us per call | of peak | where |", "|---|---|---|---|---|---|"] + rows + [""]
+        pr = {lst: _pmc_ratio(f"r5_pmc_fetch_mt_{t}_pmc_summary.csv", f"r5_pmc_write_mt_{t}_pmc_summary.csv", "mt_kernel<0", 3 * N_LIST[lst] * 4, 2)
+              for lst, t in (("resnet50", "resnet50"), ("bert_base", "bert"))}
+        if all(pr.values()):
+            L += [f"PMC traffic of `a + alpha b` per call (taken before the single-launch change, two dispatches per call; `r5_pmc_{{fetch,write}}_mt_{{resnet50,bert}}_pmc_summary.csv`): "
+                  f"ResNet-50 {pr['resnet50'][0] / 1e6:.1f} MB = {pr['resnet50'][1]:.3f} of the algorithmic bytes, BERT-base {pr['bert_base'][0] / 1e6:.1f} MB = {pr['bert_base'][1]:.3f}.", ""]
+
+    # --- kernels B and C
+    sp = _by_grid("r5_step_prior_probe_kernel_by_grid.csv")
+    c3 = _kernel_summary("r5_config3_resnet50_seethrough_kernel_summary.txt")
+    rows = []
+    for kname, wgs, calls, avg, med in sp:
+        if kname.startswith("candidate_step") or kname.startswith("tv_norm"):
+            B = 8 if wgs in (1176, 392, 1568, 2048) else 1
+            nbytes = (8 if "true, false" in kname else 8) * B * 150528 * 4 if kname.startswith("candidate_step") else 2 * B * 150528 * 4
+            rows.append(f"| `{kname}` | B = {B} ({wgs} workgroups) | {avg:.2f} | {nbytes / 1e6:.1f} MB -> {nbytes / avg / 1e3:.0f} GB/s |")
+    if rows:
+        L += ["**Kernels B and C alone** (rocprofv3, `r5_step_prior_probe_kernel_by_grid.csv`; 3 x 224 x 224 images; kernel B: 8 P 4 bytes -- hard sign with the best copy taken, or plain Adam with the noise operand; kernel C: 2 P 4):", "",
+              "| kernel | size | avg us | bytes -> rate |", "|---|---|---|---|"] + rows + [""]
+    if c3:
+        kb = next((v for k, v in c3.items() if k.startswith("candidate_step")), None)
+        kc = next((v for k, v in c3.items() if k.startswith("tv_norm")), None)
+        if kb and kc:
+            L += [f"Inside the see-through loop at B = 8 (`r5_config3_resnet50_seethrough_kernel_summary.txt`): kernel B {kb[1]:.2f} us (round 4: 11.4-11.9), kernel C {kc[1]:.2f} us (round 4: 8.2-8.5).", ""]
+
+    # --- in-loop durations, bench command
+    ks = _kernel_summary("r5_bench_kernel_summary.txt")
     if ks:
-        L += ["In-loop durations of our kernels, rocprofv3 kernel trace of the bench command (`r4_bench_kernel_summary.txt`; rocprofv3 adds ~2-3 us to every dispatch it times, see the node-cost probe below):", "",
+        L += ["**In-loop durations of our kernels**, rocprofv3 kernel trace of the bench command at HEAD (`r5_bench_kernel_summary.txt`):", "",
               "| kernel | calls | avg us |", "|---|---|---|"]
-        for name, (calls, avg) in sorted(ks.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:12]:
+        for name, (calls, avg) in sorted(ks.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:14]:
             L.append(f"| `{name}` | {calls} | {avg:.2f} |")
         L.append("")
-    # --- gap census
-    rows = []
-    for tag, label in (("r4_1trial_gap_census.json", "round-3 form (BatchNorm, ReLU, residual add separate)"),
-                       ("r4_1trial_fused_gap_census.json", "BatchNorm + residual + ReLU in kernel E"),
-                       ("r4_1trial_head_gap_census.json", "... and the second gradient of each BatchNorm input folded into the launch (HEAD, default)"),
-                       ("r4_1trial_gemm0_gap_census.json", "MIOPEN_DEBUG_CONV_GEMM=0")):
-        c = _json_line(tag)
-        if c and c.get("per_queue"):
-            q = next(iter(c["per_queue"].values()))
-            rows.append(f"| {label} | {q['dispatches_per_iter']:.0f} | {q['kernel_us_per_iter']:.0f} | {q['gap_us_per_iter']:.0f} | {q['wall_us_per_iter']:.0f} | `{tag}` |")
-    if rows:
-        L += ["Gap census of the replayed iteration under rocprofv3 (per iteration, one trial):", "",
-              "| variant | dispatches | sum of dispatch durations, us | sum of gaps, us | wall, us | file |", "|---|---|---|---|---|---|"] + rows + [""]
-    probe = _jsonl("r4_node_cost_probe.jsonl")
-    if probe:
-        L += ["Cost of ONE node of a replayed hipGraph without a profiler (`r4_node_cost_probe.jsonl`, 600-node chains):", "",
-              "| chain | us per node, graph replay | us per node, eager |", "|---|---|---|"]
-        for p in probe:
-            L.append(f"| {p['chain']} | {p['graph_us_per_node']:.2f} | {p['eager_us_per_node']:.2f} |")
-        L.append("")
-    pipes = _jsonl("r4_inflight_pipes_probe.jsonl")
-    if pipes:
-        L += ["Trials in flight by WHICH streams carry them (`r4_inflight_pipes_probe.jsonl`; streams numbered in creation order, fresh process each):", "",
-              "| busy streams | trial-iterations / s | ms per round |", "|---|---|---|"]
-        for p in pipes:
-            if "use" in p and "trial_iterations_per_s" in p:
-                L.append(f"| {', '.join(str(u) for u in p['use'])} | {p['trial_iterations_per_s']:.1f} | {p['ms_per_round']:.2f} |")
-        L.append("")
-    # --- kernel D backward A/B
-    t1, t0 = _kernel_summary("r4_config3_fused_tap_1_kernel_summary.txt"), _kernel_summary("r4_config3_fused_tap_0_kernel_summary.txt")
-    if t1 and t0:
-        L += ["DeepInversion backward inside kernel E's backward launch vs round 3's launch per layer (ResNet-50, B = 8, same box; `r4_config3_fused_tap_{1,0}_kernel_summary.txt`):", "",
-              "| kernel | fused: calls, avg us | separate: calls, avg us |", "|---|---|---|"]
-        for name in ("bn_bwd_acc_kernel", "bn_eval_bwd_kernel", "bn_eval_bwd_bwd_kernel", "bn_eval_fwd_kernel", "bn_finalize_kernel<1024>"):
-            a, c = t1.get(name), t0.get(name)
-            L.append(f"| `{name}` | {'absent' if a is None else f'{a[0]}, {a[1]:.2f}'} | {'absent' if c is None else f'{c[0]}, {c[1]:.2f}'} |")
-        f_plain, f_tap = _pmc("r4_pmc_fetch_bneval_plain_pmc_summary.csv", "bn_eval_bwd_kernel"), _pmc("r4_pmc_fetch_bneval_tap_pmc_summary.csv", "bn_eval_bwd_kernel")
-        w_plain, w_tap = _pmc("r4_pmc_write_bneval_plain_pmc_summary.csv", "bn_eval_bwd_kernel"), _pmc("r4_pmc_write_bneval_tap_pmc_summary.csv", "bn_eval_bwd_kernel")
-        if None not in (f_plain, f_tap, w_plain, w_tap):
-            L += ["", f"PMC per `bn_eval_bwd_kernel` launch (average over the 53 layers, KB): FETCH_SIZE {f_plain:.0f} without / {f_tap:.0f} with the term riding along; WRITE_SIZE {w_plain:.0f} / {w_tap:.0f} (`r4_pmc_{{fetch,write}}_bneval_{{plain,tap}}_pmc_summary.csv`)."]
+    c = _json_line("r5_1trial_gap_census.json")
+    if c and c.get("per_queue"):
+        q = next(iter(c["per_queue"].values()))
+        L += [f"Gap census of the replayed iteration under rocprofv3 (`r5_1trial_gap_census.json`): {q['dispatches_per_iter']:.0f} dispatches, {q['kernel_us_per_iter']:.0f} us of dispatch durations + {q['gap_us_per_iter']:.0f} us of gaps = {q['wall_us_per_iter']:.0f} us per iteration under the profiler.", ""]
+
+    # --- the end-of-run statistics: same-GPU control and the larger HIP sample
+    ctl, big, ref32 = _json_line("r5_control_same_gpu_torch_8starts.json"), _json_line("r5_hip_64starts_1000its.json"), _json_line("r5_reference_cpu_1000its_more_starts.json")
+    if ctl and big:
+        L += ["**End-of-run statistics of configs[1] at 1 000 iterations** (mean +- sd over starts <= 16 ulp apart; `r5_control_same_gpu_torch_8starts.json`, `r5_hip_64starts_1000its.json`" +
+              (", `r5_reference_cpu_1000its_more_starts.json`" if ref32 else "") + "):", "",
+              "| quantity | unmodified reference, CPU (n = 8) |" + (f" unmodified reference, CPU (n = {ref32['n']}) |" if ref32 else "") + " oracle/restate.py with PyTorch-ROCm ops on the GPU (n = 8) | HIP, the same 8 starts | HIP, 64 starts |",
+              "|---|---|" + ("---|" if ref32 else "") + "---|---|---|"]
+        for key in ("loss@373", "loss@624", "loss@999", "opt_value", "psnr"):
+            q = ctl["quantities"][key]
+            hb = big["hip"][key]
+            extra = ""
+            if ref32:
+                e = ref32["quantities"][key]
+                extra = f" {e['mean']:.6f} +- {e['sd']:.6f} |"
+            L.append(f"| {key} | {q['reference_cpu_mean']:.6f} +- {q['reference_cpu_sd']:.6f} |{extra} {q['torch_on_gpu_mean']:.6f} +- {q['torch_on_gpu_sd']:.6f} | {q['hip_mean']:.6f} +- {q['hip_sd']:.6f} | {hb['mean']:.6f} +- {hb['sd']:.6f} |")
         L.append("")
     L.append(END)
     return "\n".join(L)

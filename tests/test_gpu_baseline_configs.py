@@ -4,12 +4,14 @@
               inside the run): teacher forcing at the reference's own late iterates (loss AND sign of d total/dx) + statistical
               equivalence of the end of run (final loss, opt_value, PSNR) against the reference's OWN distribution over 8
               starting points <= 16 ulp apart; and the STATED horizon of 24 000 iterations (milestones 8998 / 15000 / 21015):
-              teacher forcing at iterates up to k = 23 990 and three full-length runs against the reference's three.
+              teacher forcing at iterates up to k = 23 990 and four full-length runs against the reference's eight.
   configs[2]  ResNet-50, batch 8, see-through-gradients + DeepInversion, Langevin noise ON (identical noise on both sides),
-              labels recovered with `yin`, user BN buffers.
+              labels recovered with `yin`, user BN buffers: 12 iterations with a short warm-up, and 300 iterations on the
+              SHIPPED schedule (warm-up 50, cosine decay).
   configs[3]  trial-parallel restarts: `reconstruct` with num_trials=4 sharded over two worker ranks (both on cuda:0, gloo)
               gives the single-rank result.
-  configs[4]  BERT-base (109.5 M parameters), sequence length 32, TAG joint attack: 201 of 202 tensors, AdamW, clipping.
+  configs[4]  BERT-base (109.5 M parameters), sequence length 32, TAG joint attack: 201 of 202 tensors, AdamW, clipping: 12
+              iterations, and the whole 1 000-iteration run of tag.yaml as shipped (warm-up 50, linear decay).
 
 Reference side: unmodified reference run on CPU by oracle/make_golden.py (golden_resnet18_long, golden_seethrough_b8,
 golden_tag_bert_base); fixtures under tests/golden/.  Tolerances: north_star's 1e-4 relative on losses and 0.1 dB on PSNR
@@ -191,7 +193,10 @@ def _step_direction_report(case, cfg, k, x, sign_ref, grad_ref, twin_agree, twin
         bad.append(f"k={k}: weighted sign agreement {wagree:.5f} vs reference twins {twin_wagree:.5f}")
     if 1 - step_same > 3 * (1 - twin_agree) + 1e-3:
         bad.append(f"k={k}: first step equal on {step_same:.5f} of the pixels")
-    if cosine < 1 - 10 * (1 - twin_wagree) - 1e-3 or not (0.98 <= norm_ratio <= 1.02):
+    # size as well as direction: the fixtures store the reference's gradient bf16 ROUND-TO-NEAREST (round 5; truncation before, which
+    # biased every norm by 0.3 % and needed a 2 % band): a 1 % scale error in d total/dx -- invisible to hard sign, fatal for the
+    # see-through and TAG configurations -- fails here
+    if cosine < 1 - 10 * (1 - twin_wagree) - 1e-3 or not (0.998 <= norm_ratio <= 1.002):
         bad.append(f"k={k}: gradient cosine {cosine:.6f}, norm ratio {norm_ratio:.4f}")
     return loss, bad
 
@@ -254,30 +259,32 @@ def test_resnet18_24k_teacher_forced_loss_and_step_direction(golden_dir, resnet1
 
 
 def test_resnet18_24k_end_of_run_against_the_reference_runs(golden_dir, resnet18_case):
-    """Three HIP runs of the full 24 000 iterations from the reference's three starting points (nominal x0 and two starts
-    <= 16 ulp away), in flight together on the GPU, against the three runs of the unmodified reference: the loss right after
-    each milestone, the final loss, the rescored opt_value and PSNR.  Hard-sign Adam on a ReLU network is chaotic (the
-    reference's own three runs differ from each other; over EIGHT starts its end-of-run loss has a standard deviation of
-    1.7 %, tests/golden/attack_resnet18_long.npz), and three samples underestimate that spread (at iteration 999 they
-    happen to lie within 1.3 % of each other while eight HIP starts cover 3.5 %, profiles/r4_config1_24k_8starts.log), so
-    each HIP value must lie in the reference's range widened by 3 of its standard deviations or 5 % (= 3 sigma of the
-    eight-run spread), whichever is larger, the means must agree within 4 standard errors, and mean PSNR within 0.1 dB or the
-    reference's own spread, whichever is larger.  The tight checks of this horizon are the teacher-forced ones above; the
-    8-start version of this comparison: scripts/config_runs.py --only 24k --starts 8."""
+    """Four HIP runs of the full 24 000 iterations from the reference's first four starting points (nominal x0 and starts <= 16 ulp
+    away), in flight together on the GPU, against EIGHT full-length runs of the unmodified reference (round 5; three in round 4,
+    when this gate had to be widened to 5 % because three samples under-estimate an eight-run spread): the loss right after each
+    milestone, the final loss, the rescored opt_value and PSNR.  Hard-sign Adam on a ReLU network is chaotic (the reference's own
+    runs differ from each other by +- 1.7 % at the end), so the reference's DISTRIBUTION is the yardstick: every HIP value inside
+    the reference's range widened by 3 of its own standard deviations (no floor), means within 4 standard errors, mean PSNR within
+    0.1 dB or the reference's own spread, and -- against a small offset of one sign at every mark, which each single mark would let
+    through -- the standardised mean differences POOLED over the marks within +- 3 (the marks of one run are strongly correlated,
+    so their average is held to the bound of a single standard normal, not to 3 / sqrt(marks)).  The tight checks of this horizon
+    are the teacher-forced ones above; eight HIP starts against the eight: scripts/config_runs.py --only 24k --starts 8
+    (profiles/r5_config1_24k_8starts.json)."""
     from breaching_amd import get_attack_config, prepare_attack
     from breaching_amd.cases import initial_candidate, psnr, ulp_perturb
 
     gold = _gold_24k(golden_dir)
     case = resnet18_case
-    its, n_twins = int(gold["iterations"]), gold["twin_history"].shape[0]
+    its, n_ref, n_hip = int(gold["iterations"]), gold["twin_history"].shape[0] + 1, 4
+    assert n_ref >= 8, "the fixture should hold the nominal run and seven twins (oracle/make_golden.py --only resnet18_24k)"
     device = torch.device("cuda:0")
     starts = {}
-    for idx in range(n_twins + 1):
+    for idx in range(n_hip):
         x0 = initial_candidate(case.data_cfg, 1)
         if idx > 0:
             x0 = ulp_perturb(x0, 16, torch.Generator().manual_seed(int(gold["twin_seed"]) + idx))
         starts[idx] = x0
-    cfg = get_attack_config("invertinggradients", [f"optim.max_iterations={its}", "optim.callback=4000", f"restarts.num_trials={n_twins + 1}"])
+    cfg = get_attack_config("invertinggradients", [f"optim.max_iterations={its}", "optim.callback=4000", f"restarts.num_trials={n_hip}"])
     attacker = prepare_attack(case.model, case.loss_fn, cfg, dict(device=device, dtype=torch.float))
     # every trial from its own prescribed start (the mechanism trial workers receive theirs through); per-trial candidates and
     # scores are read where `reconstruct` computes them
@@ -295,7 +302,7 @@ def test_resnet18_24k_end_of_run_against_the_reference_runs(golden_dir, resnet18
     rec, stats = attacker.reconstruct(case.server_payload, shared, {})
     assert stats["execution"]["trials"] == {t: "hipGraph replay" for t in starts}
     hists = np.stack([np.asarray(stats[f"Trial_{t}_Val"]) for t in starts])
-    assert hists.shape == (n_twins + 1, its) and len(scored) == n_twins + 1
+    assert hists.shape == (n_hip, its) and len(scored) == n_hip
     np.testing.assert_allclose(hists[0, :3], gold["history"][:3], rtol=LOSS_RTOL)  # the reproducible prefix of the nominal run: strict
     assert stats["opt_value"] == pytest.approx(min(s for _, s in scored), rel=1e-6)
     ref_hist = np.concatenate([gold["history"][None, :], gold["twin_history"]], axis=0).astype(np.float64)
@@ -306,18 +313,25 @@ def test_resnet18_24k_end_of_run_against_the_reference_runs(golden_dir, resnet18
     ref["psnr"] = np.concatenate([[gold["psnr"]], gold["twin_psnr"]])
     hip["opt_value"] = np.asarray([s for _, s in scored])
     hip["psnr"] = np.asarray([psnr(c, case.true_user_data["data"], case.data_cfg) for c, _ in scored])
-    failures = []
+    failures, z_marks = [], []
     for name, r in ref.items():
         h = np.asarray(hip[name], dtype=np.float64)
         mr, mh, sr, sh = r.mean(), h.mean(), r.std(ddof=1), h.std(ddof=1)
         se = np.sqrt(sr ** 2 / len(r) + sh ** 2 / len(h))
-        print(f"  {name:12s} reference {mr:.6f} +- {sr:.6f} [{r.min():.6f}, {r.max():.6f}]   hip {mh:.6f} +- {sh:.6f} "
-              f"[{h.min():.6f}, {h.max():.6f}]   mean diff {abs(mh - mr) / max(se, 1e-30):.2f} standard errors")
-        widen = max(3 * sr, 0.05 * abs(mr)) if name != "psnr" else max(3 * sr, PSNR_TOL_DB)
+        z = (mh - mr) / max(se, 1e-30)
+        if name.startswith("loss@"):
+            z_marks.append(z)
+        print(f"  {name:12s} reference (n = {len(r)}) {mr:.6f} +- {sr:.6f} [{r.min():.6f}, {r.max():.6f}]   hip (n = {len(h)}) {mh:.6f} +- {sh:.6f} "
+              f"[{h.min():.6f}, {h.max():.6f}]   mean difference {z:+.2f} standard errors")
+        widen = 3 * sr if name != "psnr" else max(3 * sr, PSNR_TOL_DB)
         if h.min() < r.min() - widen or h.max() > r.max() + widen:
             failures.append(f"{name}: a run lies outside the reference range [{r.min():.6f}, {r.max():.6f}] widened by {widen:.6f}")
         if abs(mh - mr) > max(4.0 * se, 1e-4 * abs(mr)) and name != "psnr":
-            failures.append(f"{name}: means differ by {abs(mh - mr) / se:.1f} standard errors")
+            failures.append(f"{name}: means differ by {z:+.1f} standard errors")
+    pooled = float(np.mean(z_marks))
+    print(f"  pooled over the {len(z_marks)} loss marks: mean standardised difference {pooled:+.2f}")
+    if abs(pooled) > 3.0:
+        failures.append(f"one-signed offset: the standardised mean differences average {pooled:+.2f} over the {len(z_marks)} marks")
     if abs(hip["psnr"].mean() - ref["psnr"].mean()) > max(PSNR_TOL_DB, ref["psnr"].max() - ref["psnr"].min()):
         failures.append(f"psnr: mean {hip['psnr'].mean():.4f} dB vs reference {ref['psnr'].mean():.4f} dB")
     assert not failures, failures
