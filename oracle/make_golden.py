@@ -595,6 +595,36 @@ def golden_resnet18_long(parallel=4):
     np.savez_compressed(os.path.join(GOLDEN, "attack_resnet18_long.npz"), **main)
 
 
+def reference_more_starts_report(first=8, last=31, out_name="r5_reference_cpu_1000its_more_starts.json"):
+    """Round 5: a LARGER sample of the reference's own end-of-run distribution at 1000 iterations (starts idx 8 ... 31, each <= 16 ulp
+    from x0, seeded like the eight of attack_resnet18_long.npz), produced by `--long-worker IDX oracle/_long/longIDX.npz`; together
+    with the fixture's eight: what the HIP distribution over 64 starts (profiles/r5_hip_64starts_1000its.json) is compared with.
+    Written under profiles/ (evidence, not a test fixture)."""
+    import json
+
+    gold = np.load(os.path.join(GOLDEN, "attack_resnet18_long.npz"))
+    hists = [gold["history"]] + list(gold["twin_history"])
+    opts = [float(gold["opt_value"])] + [float(v) for v in gold["twin_opt_value"]]
+    psnrs = [float(gold["psnr"])] + [float(v) for v in gold["twin_psnr"]]
+    used = list(range(8))
+    for idx in range(first, last + 1):
+        path = os.path.join(FULL_DIR, f"long{idx}.npz")
+        if os.path.exists(path):
+            run = np.load(path)
+            hists.append(run["history"]), opts.append(float(run["opt_value"])), psnrs.append(float(run["psnr"])), used.append(idx)
+    marks = (373, 380, 624, 630, 874, 880, 999)
+    cols = {f"loss@{m}": np.asarray([h[m] for h in hists], dtype=np.float64) for m in marks}
+    cols["opt_value"], cols["psnr"] = np.asarray(opts), np.asarray(psnrs)
+    report = dict(n=len(used), starts=used, iterations=1000,
+                  source="unmodified reference on CPU (oracle/make_golden.py --long-worker), starts <= 16 ulp from x0",
+                  quantities={k: dict(mean=float(v.mean()), sd=float(v.std(ddof=1)), values=[round(float(x), 6) for x in v]) for k, v in cols.items()})
+    with open(os.path.join(ROOT, "profiles", out_name), "w") as f:
+        json.dump(report, f, indent=1)
+    for k, v in cols.items():
+        print(f"  {k:10s} reference {v.mean():.6f} +- {v.std(ddof=1):.6f} (n = {len(v)}, standard error {v.std(ddof=1) / np.sqrt(len(v)):.6f})")
+    return report
+
+
 # ---- BASELINE configs[1] at its STATED horizon: 24 000 iterations --------------------------------------------------
 FULL_ITERS = 24000  # invertinggradients.yaml:19; step-lr milestones at 8998 / 15000 / 21015 (common.py:22-27)
 FULL_TWINS = 7      # + the nominal start: eight unmodified-reference runs (round 4: three; 2.5 h each at 2 threads, 4.7 h at 1)
@@ -1208,9 +1238,12 @@ STEPS = dict(configs=golden_configs, kernels=golden_kernels, schedules=golden_sc
              resnet18_long=golden_resnet18_long, seethrough_b8=golden_seethrough_b8, tag_bert_base=golden_tag_bert_base,
              pearlmutter=golden_pearlmutter, resnet18_24k=golden_resnet18_24k, seethrough_noise=golden_seethrough_noise,
              resnet18_long_signs=golden_resnet18_long_signs, tag_bert_base_1000=golden_tag_bert_base_1000,
-             seethrough_b8_long=golden_seethrough_b8_long)
+             seethrough_b8_long=golden_seethrough_b8_long, reference_more_starts=reference_more_starts_report,
+             assemble_resnet18_24k=lambda: assemble_resnet18_24k(), assemble_tag_1000=lambda: assemble_tag_bert_base_1000(),
+             assemble_seethrough_long=lambda: assemble_seethrough_b8_long())
 SLOW_STEPS = ("resnet18_long", "seethrough_b8", "tag_bert_base", "resnet18_24k", "seethrough_noise", "resnet18_long_signs",
-              "tag_bert_base_1000", "seethrough_b8_long")  # hours of CPU: only run when asked for by name
+              "tag_bert_base_1000", "seethrough_b8_long", "reference_more_starts", "assemble_resnet18_24k", "assemble_tag_1000",
+              "assemble_seethrough_long")  # hours of CPU: only run when asked for by name
 
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
@@ -1225,7 +1258,7 @@ if __name__ == "__main__":
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
     if args.long_worker is not None:
-        _resnet18_long_worker(int(args.long_worker[0]), args.long_worker[1])
+        _resnet18_long_worker(int(args.long_worker[0]), args.long_worker[1], threads=args.threads)
         sys.exit(0)
     if args.seethrough_worker is not None:
         _seethrough_b8_long_worker(int(args.seethrough_worker[0]), args.seethrough_worker[1], threads=args.threads,

@@ -27,7 +27,7 @@ import sys
 
 FAMILIES = [  # first match wins
     ("ours: kernel A (gm_*)", r"gm_(fwd|bwd|finalize|pack)_kernel"),
-    ("ours: kernel B/C, commit (step, tv, loss)", r"candidate_step_kernel|tv_norm_kernel|loss_commit_kernel|grad_sumsq|grad_norm_finalize|state_reset"),
+    ("ours: kernel B/C, commit (step, tv, loss)", r"candidate_step(_vec4)?_kernel|tv_norm(_vec4)?_kernel|loss_commit_kernel|grad_sumsq|grad_norm_finalize|state_reset"),
     ("ours: kernel D (bn_sums/finalize/bwd)", r"bn_sums_kernel|bn_finalize_kernel|bn_bwd_kernel|bn_bwd_acc_kernel"),
     ("ours: kernel E (bn_eval_*)", r"bn_eval_"),
     ("ours: kernel F (ln_*)", r"ln_(fwd|bwd)"),
@@ -87,7 +87,7 @@ def load(path):
 
 def census_queue(rows, iters, skip_tail):
     rows = sorted(rows, key=lambda r: r["start"])
-    cuts = [i for i, r in enumerate(rows) if "candidate_step_kernel" in r["name"]]
+    cuts = [i for i, r in enumerate(rows) if re.search(r"candidate_step(_vec4)?_kernel", r["name"])]
     # one iteration = (cut[k-1], cut[k]]; joint attacks step two tensors per iteration -> cut at the last step of a burst
     merged = []
     for c in cuts:
@@ -208,12 +208,12 @@ def main():
         by_queue[r["queue"]].append(r)
     result = dict(label=args.label, trace=os.path.basename(trace), dispatches=len(rows),
                   queues={q: dict(dispatches=len(v), streams=sorted({r["stream"] for r in v}),
-                                  candidate_steps=sum("candidate_step_kernel" in r["name"] for r in v)) for q, v in by_queue.items()},
+                                  candidate_steps=sum(bool(re.search(r"candidate_step(_vec4)?_kernel", r["name"])) for r in v)) for q, v in by_queue.items()},
                   per_queue={})
     one_iteration = None
     windows = []
     for q, v in by_queue.items():
-        if sum("candidate_step_kernel" in r["name"] for r in v) < 3:
+        if sum(bool(re.search(r"candidate_step(_vec4)?_kernel", r["name"])) for r in v) < 3:
             continue
         res, one, window = census_queue(v, args.iters, args.skip_tail)
         result["per_queue"][q] = res
@@ -227,7 +227,7 @@ def main():
             attack_queues = {q: by_queue[q] for q in result["per_queue"]}
             result["queues_busy_at_once"] = concurrency(attack_queues, common)
             result["common_window_ms"] = round((common[1] - common[0]) / 1e6, 3)
-            its = sum(sum(1 for r in v if "candidate_step_kernel" in r["name"] and common[0] <= r["end"] <= common[1]) for v in attack_queues.values())
+            its = sum(sum(1 for r in v if re.search(r"candidate_step(_vec4)?_kernel", r["name"]) and common[0] <= r["end"] <= common[1]) for v in attack_queues.values())
             result["trial_iterations_in_window"] = its
             result["trial_iterations_per_s_in_window"] = round(its / ((common[1] - common[0]) / 1e9), 1)
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)

@@ -477,9 +477,12 @@ def test_resnet50_batch8_seethrough_300_iterations_on_the_shipped_schedule(golde
     (seethroughgradients.yaml:20-36) -- for 300 iterations (the horizon is the one thing shortened: the stated 20 000 would be a
     week of CPU for the reference) against three runs of the unmodified reference (oracle/make_golden.py golden_seethrough_b8_long):
     nominal, the same noise stream from a start <= 16 ulp away, and another noise stream.  Both sides add identical noise
-    (`impl.langevin_noise=host` re-creates the reference's CPU generator stream).  Plain Adam, no sign: the whole history inside
-    10x the running envelope of the reference's own twin (strict 1e-4 until that opens), PSNR within 0.1 dB, opt_value likewise, and
-    the run must sit with the same-noise twin, not with the other-noise run.  Loop: optimization_based_attack.py:110-143,167-170."""
+    (`impl.langevin_noise=host` re-creates the reference's CPU generator stream).  Plain Adam, no sign, but pixels whose gradient is
+    below the noise follow rounding through Adam's normalisation: the reference's own twin leaves the 1e-4 band at iteration 19 and
+    peaks at 1.4e-3 (a run with ANOTHER noise stream sits at 1.3e-3 in the median -- the loss history barely tells noise streams
+    apart, the reconstruction does: rms pixel distance 0.31 for the twin, 1.12 for the other stream).  Held to: strict 1e-4 while
+    the twin is, then 3x the twin's running envelope; opt_value likewise; PSNR within 0.1 dB; and the reconstruction within 2x the
+    twin's distance of the reference's and well inside the other-noise distance.  Loop: optimization_based_attack.py:110-143,167-170."""
     from breaching_amd import get_attack_config, prepare_attack
     from breaching_amd.cases import build_case, initial_candidate, parameter_checksum, psnr
 
@@ -504,7 +507,7 @@ def test_resnet50_batch8_seethrough_300_iterations_on_the_shipped_schedule(golde
     rel = np.abs(hist - ref) / np.abs(ref)
     envelope = _running_envelope(gold["twin_history"], ref)
     other = np.abs(gold["other_noise_history"].astype(np.float64) - ref) / np.abs(ref)
-    tol = np.maximum(LOSS_RTOL, 10.0 * envelope)
+    tol = np.maximum(LOSS_RTOL, 3.0 * envelope)
     first_open = int(np.argmax(envelope > LOSS_RTOL)) if (envelope > LOSS_RTOL).any() else its
     print(f"  loss {ref[0]:.3f} -> {ref[-1]:.3f} (hip {hist[-1]:.3f}); twin within 1e-4 for the first {first_open} iterations, its envelope at "
           f"the end {envelope[-1]:.2e}; hip max rel dev {rel.max():.2e} (at the end {rel[-1]:.2e}); other noise stream: median {np.median(other):.2e}")
@@ -514,12 +517,12 @@ def test_resnet50_batch8_seethrough_300_iterations_on_the_shipped_schedule(golde
     print(f"  PSNR hip {got_psnr:.4f} dB, reference {float(gold['psnr']):.4f}, its twin {float(gold['twin_psnr']):.4f}, other noise {float(gold['other_noise_psnr']):.4f}")
     assert abs(got_psnr - float(gold["psnr"])) <= PSNR_TOL_DB
     twin_opt_dev = abs(float(gold["twin_opt_value"]) / float(gold["opt_value"]) - 1)
-    assert stats["opt_value"] == pytest.approx(float(gold["opt_value"]), rel=max(LOSS_RTOL, 10.0 * twin_opt_dev))
+    assert stats["opt_value"] == pytest.approx(float(gold["opt_value"]), rel=max(LOSS_RTOL, 3.0 * twin_opt_dev))
     data = rec["data"].detach().cpu().numpy()[..., :32, :32]
     dist = lambda a: float(np.sqrt(np.mean((a - gold["rec"]) ** 2)))  # noqa: E731
     d_hip, d_twin, d_other = dist(data), dist(gold["twin_rec"]), dist(gold["other_noise_rec"])
     print(f"  rms pixel distance to the reference's reconstruction (32 x 32 crop): hip {d_hip:.3e}, reference twin {d_twin:.3e}, other noise {d_other:.3e}")
-    assert d_hip <= max(3.0 * d_twin, 0.3 * d_other)
+    assert d_hip <= 2.0 * d_twin and d_hip <= 0.6 * d_other
 
 
 # ---------------------------------------------------------------------------------------------------------------------
