@@ -455,6 +455,12 @@ def test_tag_bert_base_whole_run_at_the_shipped_schedule(golden_dir):
     print(f"  loss {ref[0]:.4f} -> {ref[-1]:.4f} (hip {hist[-1]:.4f}); {strict} of {its} iterations within 1e-4; the reference's twin stays within "
           f"1e-4 of it for the first {first_open} iterations, envelope at the end {envelope[-1]:.2e}; hip max rel dev {rel.max():.2e} at "
           f"{int(rel.argmax())}, at the end {rel[-1]:.2e}")
+    twin_dev = np.abs(gold["twin_history"].astype(np.float64) - ref) / np.abs(ref)
+    marks = [0, 5, 10, 20, 30, 50, 75, 100, 150, 200, 300, 400, 500, 600, 700, 800, 900, its - 1]
+    print("  iteration      " + " ".join(f"{m:>8d}" for m in marks))
+    print("  reference loss " + " ".join(f"{ref[m]:8.2f}" for m in marks))
+    print("  hip rel dev    " + " ".join(f"{rel[m]:8.1e}" for m in marks))
+    print("  twin rel dev   " + " ".join(f"{twin_dev[m]:8.1e}" for m in marks))
     assert (rel[:first_open] <= LOSS_RTOL).all(), f"before the reference's own twin parts: max {rel[:first_open].max():.2e}"
     assert (rel <= tol).all(), f"{int((rel > tol).sum())} iterations outside the envelope, worst {float((rel / tol).max()):.1f}x at {int((rel / tol).argmax())}"
     twin_opt_dev = abs(float(gold["twin_opt_value"]) / float(gold["opt_value"]) - 1)
