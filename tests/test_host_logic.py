@@ -623,7 +623,7 @@ def test_pending_batchnorm_absorbs_residual_and_relu_without_changing_the_model(
 
 
 def test_design_tables_are_generated_from_the_committed_profiles():
-    """DESIGN.md section 6's round-4 tables are the output of scripts/design_tables.py over the files under profiles/: a number
+    """DESIGN.md section 6's round-5 tables are the output of scripts/design_tables.py over the files under profiles/: a number
     in the text cannot drift from the committed evidence (round 3 had a quoted 40.2 / 47.6 us that the summary file no longer
     showed).  Regenerate with `python scripts/design_tables.py --write`."""
     import importlib.util
@@ -638,8 +638,11 @@ def test_design_tables_are_generated_from_the_committed_profiles():
     block = text[text.index(module.BEGIN): text.index(module.END) + len(module.END)]
     assert block == module.build(), "DESIGN.md is stale: run `python scripts/design_tables.py --write`"
     # the files the block quotes exist
-    for name in ("r4_bench_n1.json", "r4_1trial_gap_census.json", "r4_node_cost_probe.jsonl", "r4_inflight_pipes_probe.jsonl",
-                 "r4_bench_kernel_summary.txt"):
+    import re
+
+    quoted = set(re.findall(r"`(r5_[A-Za-z0-9_.]+\.(?:json|jsonl|txt|csv))`", block))
+    assert len(quoted) >= 12, quoted
+    for name in quoted | {"r5_bench_driver_style.json", "r5_bench_kernel_summary.txt", "r5_read_ceiling_probe.jsonl", "r5_hip_64starts_1000its.json"}:
         assert os.path.exists(os.path.join(root, "profiles", name)), name
 
 
