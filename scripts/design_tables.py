@@ -258,19 +258,42 @@ def build():
 
     # --- the end-of-run statistics: same-GPU control and the larger HIP sample
     ctl, big, ref32 = _json_line("r5_control_same_gpu_torch_8starts.json"), _json_line("r5_hip_64starts_1000its.json"), _json_line("r5_reference_cpu_1000its_more_starts.json")
+    more = _json_line("r5_torch_on_gpu_24_more_starts.json")
     if ctl and big:
-        L += ["**End-of-run statistics of configs[1] at 1 000 iterations** (mean +- sd over starts <= 16 ulp apart; `r5_control_same_gpu_torch_8starts.json`, `r5_hip_64starts_1000its.json`" +
-              (", `r5_reference_cpu_1000its_more_starts.json`" if ref32 else "") + "):", "",
-              "| quantity | unmodified reference, CPU (n = 8) |" + (f" unmodified reference, CPU (n = {ref32['n']}) |" if ref32 else "") + " oracle/restate.py with PyTorch-ROCm ops on the GPU (n = 8) | HIP, the same 8 starts | HIP, 64 starts |",
-              "|---|---|" + ("---|" if ref32 else "") + "---|---|---|"]
+        import math
+
+        marks = (373, 380, 624, 630, 874, 880, 999)
+        files = "`r5_control_same_gpu_torch_8starts.json`, `r5_hip_64starts_1000its.json`" + (", `r5_reference_cpu_1000its_more_starts.json`" if ref32 else "") + (", `r5_torch_on_gpu_24_more_starts.json`" if more else "")
+        L += [f"**End-of-run statistics of configs[1] at 1 000 iterations** (mean +- sd over starts <= 16 ulp apart; {files}).  Last column: difference of the two GPU implementations' means and of HIP's from the larger CPU sample, in standard errors:", "",
+              "| quantity | unmodified reference, CPU (n = 8) |" + (f" unmodified reference, CPU (n = {ref32['n']}) |" if ref32 else "") +
+              " oracle/restate.py with PyTorch-ROCm ops on the GPU (n = 8) |" + (" ... (n = 32) |" if more else "") + " HIP, the same 8 starts | HIP, 64 starts | HIP - torch on GPU / HIP - CPU reference |",
+              "|---|---|" + ("---|" if ref32 else "") + "---|" + ("---|" if more else "") + "---|---|---|"]
         for key in ("loss@373", "loss@624", "loss@999", "opt_value", "psnr"):
             q = ctl["quantities"][key]
             hb = big["hip"][key]
-            extra = ""
+            cells = [f"{q['reference_cpu_mean']:.6f} +- {q['reference_cpu_sd']:.6f}"]
+            ref_stat = (q["reference_cpu_mean"], q["reference_cpu_sd"], 8)
             if ref32:
                 e = ref32["quantities"][key]
-                extra = f" {e['mean']:.6f} +- {e['sd']:.6f} |"
-            L.append(f"| {key} | {q['reference_cpu_mean']:.6f} +- {q['reference_cpu_sd']:.6f} |{extra} {q['torch_on_gpu_mean']:.6f} +- {q['torch_on_gpu_sd']:.6f} | {q['hip_mean']:.6f} +- {q['hip_sd']:.6f} | {hb['mean']:.6f} +- {hb['sd']:.6f} |")
+                cells.append(f"{e['mean']:.6f} +- {e['sd']:.6f}")
+                ref_stat = (e["mean"], e["sd"], ref32["n"])
+            cells.append(f"{q['torch_on_gpu_mean']:.6f} +- {q['torch_on_gpu_sd']:.6f}")
+            torch_stat = (q["torch_on_gpu_mean"], q["torch_on_gpu_sd"], 8)
+            if more:
+                first = [r["history"][marks.index(int(key[5:]))] if key.startswith("loss@") else r[key] for r in ctl["runs"]["torch_on_gpu"]]
+                vals = first + list(more["torch_on_gpu"][key]["values"])
+                mean = sum(vals) / len(vals)
+                sd = math.sqrt(sum((v - mean) ** 2 for v in vals) / (len(vals) - 1))
+                cells.append(f"{mean:.6f} +- {sd:.6f}")
+                torch_stat = (mean, sd, len(vals))
+            cells += [f"{q['hip_mean']:.6f} +- {q['hip_sd']:.6f}", f"{hb['mean']:.6f} +- {hb['sd']:.6f}"]
+
+            def z(a, b):
+                return (a[0] - b[0]) / math.sqrt(a[1] ** 2 / a[2] + b[1] ** 2 / b[2])
+
+            hip_stat = (hb["mean"], hb["sd"], hb["n"])
+            cells.append(f"{z(hip_stat, torch_stat):+.1f} / {z(hip_stat, ref_stat):+.1f}")
+            L.append(f"| {key} | " + " | ".join(cells) + " |")
         L.append("")
     L.append(END)
     return "\n".join(L)

@@ -64,6 +64,7 @@ pmc_mt()       { pmc mt_resnet50; pmc mt_bert; }
 cfg24k()   { timeout 900 python scripts/config_runs.py --only 24k --starts 8 > $OUT/${TAG}_config1_24k_8starts.log 2>&1; tail -1 $OUT/${TAG}_config1_24k_8starts.log > $OUT/${TAG}_config1_24k_8starts.json; grep "hip .* reference" $OUT/${TAG}_config1_24k_8starts.log | cut -c1-250; }
 configs()  { timeout 1500 python scripts/config_runs.py > $OUT/${TAG}_config_runs_same_process.log 2>&1; tail -12 $OUT/${TAG}_config_runs_same_process.log | cut -c1-400; }
 control()  { timeout 900 python tests/control_same_gpu_torch.py --out $OUT/${TAG}_control_same_gpu_torch.json > $OUT/${TAG}_control_same_gpu_torch.log 2>&1; tail -14 $OUT/${TAG}_control_same_gpu_torch.log | cut -c1-260; }
+torch24()  { timeout 900 python tests/control_same_gpu_torch.py --torch-only --first-start 8 --starts 24 --processes 3 --out $OUT/${TAG}_torch_on_gpu_24_more_starts.json > $OUT/${TAG}_torch_on_gpu_24_more_starts.log 2>&1; tail -10 $OUT/${TAG}_torch_on_gpu_24_more_starts.log | cut -c1-200; }
 tagtwin()  { timeout 600 python scripts/tag_twin_probe.py > $OUT/${TAG}_tag_twin_probe.jsonl 2> $OUT/${TAG}_tag_twin_probe.err; cut -c1-600 $OUT/${TAG}_tag_twin_probe.jsonl; tail -2 $OUT/${TAG}_tag_twin_probe.err | cut -c1-200; }
 hip64()    { timeout 600 python tests/control_same_gpu_torch.py --hip-only --starts 64 --out $OUT/${TAG}_hip_64starts_1000its.json > $OUT/${TAG}_hip_64starts_1000its.log 2>&1; tail -10 $OUT/${TAG}_hip_64starts_1000its.log | cut -c1-200; }
 stepprior_trace() {

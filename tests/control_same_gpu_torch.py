@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--hip-only", action="store_true",
                     help="only the HIP runs (cheap: 64 starts x 1000 iterations take about two minutes), for a larger sample of the HIP "
                          "distribution against reference runs generated on CPU (oracle/make_golden.py --long-worker IDX OUT)")
+    ap.add_argument("--torch-only", action="store_true", help="only the torch-on-GPU runs (more starts for a firmer control sample)")
+    ap.add_argument("--first-start", type=int, default=0, help="index of the first starting point (0 = the nominal x0)")
     ap.add_argument("--processes", type=int, default=3, help="torch-on-GPU worker processes at a time (eight at once ran at 8 it/s each)")
     args = ap.parse_args()
     gold = np.load(os.path.join(ROOT, "tests", "golden", "attack_resnet18_long.npz"))
@@ -121,7 +123,7 @@ def main():
             json.dump(report, f, indent=1)
         return
     t0 = time.perf_counter()
-    torch_runs, pending, running = [], list(range(args.starts)), []
+    torch_runs, pending, running = [], list(range(args.first_start, args.first_start + args.starts)), []
     while pending or running:
         while pending and len(running) < args.processes:
             idx = pending.pop(0)
@@ -134,6 +136,15 @@ def main():
                 torch_runs.append(json.load(f))
         os.path.exists(path) and os.remove(path)
     torch_wall = time.perf_counter() - t0
+    if args.torch_only:
+        name, cols = table("torch_on_gpu", torch_runs)
+        report = dict(starts=sorted(r["idx"] for r in torch_runs), iterations=args.iterations, torch_on_gpu_wall_s=round(torch_wall, 1),
+                      torch_on_gpu={k: dict(mean=float(v.mean()), sd=float(v.std(ddof=1)), n=int(len(v)), values=[round(float(x), 6) for x in v]) for k, v in cols.items()})
+        for k, v in cols.items():
+            print(f"{k:10s} torch on GPU {v.mean():.6f} +- {v.std(ddof=1):.6f} (n = {len(v)})", flush=True)
+        with open(args.out, "w") as f:
+            json.dump(report, f, indent=1)
+        return
     hip, hip_wall = hip_runs(args.starts, args.iterations, seed)
     ref_hist = np.concatenate([gold["history"][None, :], gold["twin_history"]], axis=0)
     ref = [dict(history=h.tolist(), opt_value=float(o), psnr=float(p)) for h, o, p in
