@@ -355,7 +355,7 @@ def bn_statistic(x, running_mean, running_var, weight=1.0):
 
 
 def resolve_pending(x):
-    """A not-yet-launched eval-BatchNorm output (attacker._PendingBatchNorm) as an ordinary tensor: hooks that hand a module's
+    """A not-yet-launched eval-BatchNorm output (victim_layers._PendingBatchNorm) as an ordinary tensor: hooks that hand a module's
     input to an autograd.Function must not pass the metadata-only wrapper on (it carries no autograd edge)."""
     return x.value() if type(x).__name__ == "_PendingBatchNorm" else x
 
@@ -375,7 +375,7 @@ class _BnInputTap:
         self.module, self.record, self.layer = module, record, layer
         self.owner, self.model_idx = owner, model_idx
         self.in_producer = False  # this pass: the module's own autograd node (kernel E) carries the token, no `_BnTap` node
-        self.pending = None       # a not-yet-launched kernel E forward of this pass that will deliver the token (attacker._PendingBatchNorm)
+        self.pending = None       # a not-yet-launched kernel E forward of this pass that will deliver the token (victim_layers._PendingBatchNorm)
         self.fed = False   # this pass: the module's own forward kernel writes the layer's channel sums (no bn_sums needed)
         self.x = None      # the activation of the latest forward pass (detached view, what kernel D reads)
         self.token = None  # its token (carries the autograd edge back to the tap)

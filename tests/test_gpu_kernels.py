@@ -801,7 +801,7 @@ def test_resnet_blocks_run_fused_and_match_the_stock_modules():
     evaluations differ; the fp64 run is the referee and the stock modules' own error the yardstick)."""
     import copy
 
-    import breaching_amd.attacker as A
+    import breaching_amd.victim_layers as A
     from breaching_amd.cases import build_model
 
     for name, n_fused_relu, n_plain in (("resnet18", 17, 3), ("resnet50", 49, 4)):

@@ -506,7 +506,7 @@ def test_pending_batchnorm_absorbs_residual_and_relu_without_changing_the_model(
     BatchNorm output nobody uses)."""
     import copy
 
-    import breaching_amd.attacker as A
+    import breaching_amd.victim_layers as A
 
     calls = []
 
