@@ -100,6 +100,32 @@ def test_gm_zip_truncation_and_upstream_gradient(kernels_oracle, hip_lib):
     _assert_grads([g.cpu().numpy() for g in grads[:2]], [3.0 * g for g in want_g])
 
 
+@pytest.mark.parametrize("name", ["cosine-similarity", "euclidean", "tag-euclidean", "tag-euclidean/exp"])
+def test_gm_with_empty_and_single_element_tensors(name, kernels_oracle, hip_lib):
+    """Edge cases of the list layout: parameters with ZERO elements in the middle and at the end of the list (their gradients have
+    no storage -- a null data pointer; they contribute nothing and get an empty gradient back), single-element tensors, and a list
+    whose first tensor is empty.  Values and gradients against the fp64 C oracle evaluated on the non-empty tensors (for TAG the
+    per-tensor weights count the empty positions, objectives.py:115-125)."""
+    from oracle import kernels_ref
+
+    rng = np.random.default_rng(17)
+    shapes = [(0,), (1,), (5,), (0, 7), (4097,), (1, 1), (3, 0, 2), (4096,), (0,)]
+    rec_np = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    data_np = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    kw = dict(KIND_KW[name])
+    kind = name.split("/")[0]
+    keep = [i for i, s in enumerate(shapes) if int(np.prod(s)) > 0]
+    weights = None
+    if kind == "tag-euclidean":
+        weights = np.asarray(kernels_ref.tag_weights(len(shapes), kw.get("scale_scheme", "linear")))[keep]
+    want_v, want_g = kernels_ref.gm(kind, [rec_np[i] for i in keep], [data_np[i] for i in keep], scale=kw["scale"],
+                                    tag_scale=kw.get("tag_scale", 0.0), weights=weights)
+    value, grads = _run_hip_objective(name, kw, rec_np, data_np)
+    assert abs(value[0] - want_v) <= VALUE_RTOL * abs(want_v) + 1e-9
+    assert [g.shape for g in grads] == [tuple(s) for s in shapes]
+    _assert_grads([grads[i] for i in keep], want_g)
+
+
 def test_gm_full_size_properties(hip_lib):
     """ResNet-18 sized list (N = 11.69 M): size-independent properties at BASELINE size.
 
