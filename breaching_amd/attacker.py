@@ -22,10 +22,11 @@ import numpy as np
 import torch
 
 from . import _lib, schedules, streams as trial_streams, trials, workers
+from .config import cfg_get as _cfg_get
 from .gm import objective_lookup
 from .priors import HipNormRegularization, HipTotalVariation, launch_tv_norm, regularizer_lookup
 # the HIP layers of the private victim-model copy (kernels E / F) live in their own, frozen module; re-exported here for callers
-from .victim_layers import (FusedEpilogueError, _cfg_get, _EvalAffineBatchNorm2d, _EvalBNFunction, _EvalBNGradFunction, _HipLayerNorm,  # noqa: F401
+from .victim_layers import (FusedEpilogueError, _EvalAffineBatchNorm2d, _EvalBNFunction, _EvalBNGradFunction, _HipLayerNorm,  # noqa: F401
                             _launch_eval_bn, _LayerNormFunction, _LayerNormGradFunction, _PendingBatchNorm, _under_functorch,
                             fast_eval_bn_enabled, fast_eval_bn_mode, fast_layer_norm_enabled, fuse_bn_relu_enabled, fuse_bn_relu_policy,
                             use_affine_eval_batchnorm, use_hip_layernorm)

@@ -40,6 +40,16 @@ class AttrDict(dict):
         return AttrDict({k: copy.deepcopy(v, memo) for k, v in self.items()})
 
 
+def cfg_get(node, key, default=None):
+    """`node[key]`, or `default` when the key is absent or the node is not a mapping (cfg objects are duck-typed: Hydra DictConfig
+    in the reference's scripts, `AttrDict` here)."""
+    try:
+        value = node[key]
+    except (KeyError, AttributeError, TypeError):
+        return default
+    return value
+
+
 def deep_merge(base, override):
     """Hydra `defaults: [_default, _self_]` semantics for plain dicts: recursive, `override` wins."""
     out = copy.deepcopy(base)

@@ -21,15 +21,7 @@ batch_norm / layer_norm arithmetic through both orders, run in fp64, is the orac
 import torch
 
 from . import _lib
-
-
-def _cfg_get(node, key, default=None):
-    try:
-        value = node[key]
-    except (KeyError, AttributeError, TypeError):
-        return default
-    return value
-
+from .config import cfg_get as _cfg_get
 
 def _vector_ready(t, hw):
     """Contiguous fp32, and 16-byte aligned when the kernels will use 16-byte accesses (H*W % 4 == 0)."""
