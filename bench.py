@@ -76,6 +76,26 @@ def pmc_traffic_bytes(kernel, sources=None):
     return int(total) if found == 2 else None
 
 
+def committed_replay_duration(kernel_prefix):
+    """Average dispatch duration (us) of a kernel INSIDE the replayed hipGraph, from the newest committed rocprofv3 kernel trace of this
+    bench command (profiles/r*_bench_kernel_summary.txt).  bench.py's own event pairs ride on eager launches -- a replayed graph cannot
+    carry them -- and the same kernels run ~7 % faster inside the replay (no idle gaps between dispatches); rocprofv3 of the eager
+    bench agrees with the events within 1 % (profiles/r5_bench_eager_kernel_summary.txt).  None when no trace is committed."""
+    import glob
+    import re
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_kernel_summary.txt")))
+    if not paths:
+        return None, None
+    with open(paths[-1]) as f:
+        for line in f:
+            if line.startswith(kernel_prefix):
+                m = re.search(r"avg=\s*([0-9.]+)us", line)
+                if m:
+                    return float(m.group(1)), os.path.basename(paths[-1])
+    return None, None
+
+
 def bert_base_gradient_shapes():
     """The 201 gradient tensors a TAG attack on BERT-base (MLM head, vocabulary 30 522) matches: every parameter but the
     word-embedding matrix (base_attack.py:94 pops it).  86 073 402 elements (SURVEY.md section 8 size table)."""
@@ -583,6 +603,11 @@ def main():
                         # both gradient lists (2 x 46.8 MB for ResNet-18) fit the 256 MiB Infinity Cache and `r` was just
                         # written by autograd: the achieved rate is partly a cache figure, not pure HBM
                         infinity_cache_resident=bool(fwd_bytes <= 256 * 2 ** 20))
+        replay_us, replay_file = committed_replay_duration("gm_fwd_kernel<0")
+        if replay_us and args.model == "resnet18":
+            roofline["in_graph_replay"] = dict(avg_launch_us=replay_us, frac=round(fwd_bytes / replay_us / 1e3 / HBM_PEAK_GBS, 4),
+                                               source=f"rocprofv3 kernel trace of this command, committed ({replay_file}): the timed region replays a hipGraph, where "
+                                                      "event pairs cannot ride; the events above time the same kernel on eager launches")
         if "fin" in kernels:  # the whole forward stage: reduction + one-workgroup finalize
             stage_us = k["avg_us"] + kernels["fin"]["avg_us"]
             roofline.update(stage_us=round(stage_us, 2), stage_GBs=round(fwd_bytes / (stage_us * 1e-6) / 1e9, 1),

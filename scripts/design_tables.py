@@ -130,6 +130,11 @@ def build():
         if ce.get("us"):
             L.append(f"| `roofline.ceiling`: bare read of the same bytes with kernel A's grid and loads, behind a writer, same events, same run | {ce['us']:.2f} us = {ce['GBs']:.0f} GB/s ({ce['behind_writer']['frac_of_hbm_peak']:.3f} of 8 TB/s; warm {ce['warm']['median_us']:.2f} us) -> kernel A forward at **{r.get('frac_of_ceiling', 0):.2f} of the measured ceiling** |")
         L.append(f"| kernel A backward ({k['bwd']['algorithmic_bytes'] / 1e6:.1f} MB) | {k['bwd']['avg_us']:.2f} us -> {k['bwd']['achieved_GBs']:.0f} GB/s = **{k['bwd']['frac_of_hbm_peak']:.3f}** |")
+        eager = _kernel_summary("r5_bench_eager_kernel_summary.txt")
+        replay = _kernel_summary("r5_bench_kernel_summary.txt")
+        fk, bk = "gm_fwd_kernel<0, false>", "gm_bwd_kernel<0, false, false>"
+        if fk in eager and fk in replay:
+            L.append(f"| the same two kernels by rocprofv3, by launch mode: `bench.py --no-graph` (eager launches -- the mode the event-timed iterations above run in, a replayed graph cannot carry event pairs; `r5_bench_eager_kernel_summary.txt`) / inside graph replay (`r5_bench_kernel_summary.txt`) | forward {eager[fk][1]:.2f} / {replay[fk][1]:.2f} us = {_frac(r['algorithmic_bytes'], eager[fk][1]):.3f} / **{_frac(r['algorithmic_bytes'], replay[fk][1]):.3f}**; backward {eager[bk][1]:.2f} / {replay[bk][1]:.2f} us = {_frac(k['bwd']['algorithmic_bytes'], eager[bk][1]):.3f} / **{_frac(k['bwd']['algorithmic_bytes'], replay[bk][1]):.3f}** -- events and rocprofv3 agree within {abs(eager[fk][1] / r['avg_launch_us'] - 1) * 100:.0f} % in the same launch mode; inside the replayed graph (the timed region) the kernels are {(1 - replay[fk][1] / eager[fk][1]) * 100:.0f} % faster |")
         if r.get("traffic") and k["bwd"].get("traffic"):
             L.append(f"| PMC traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE; committed passes at HEAD), forward / backward | {r['traffic'] / 1e6:.2f} MB vs {r['algorithmic_bytes'] / 1e6:.2f} MB (**{r['traffic'] / r['algorithmic_bytes']:.3f}**) / {k['bwd']['traffic'] / 1e6:.2f} vs {k['bwd']['algorithmic_bytes'] / 1e6:.2f} MB (**{k['bwd']['traffic'] / k['bwd']['algorithmic_bytes']:.3f}**) |")
         h = r.get("hbm_resident") or {}

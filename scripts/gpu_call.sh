@@ -47,6 +47,9 @@ trace_bench()  {
   trace=$(ls -S $(find /tmp/prof_${TAG}_bench -name "*kernel_trace.csv") | head -1)
   [ -n "$trace" ] && python scripts/gap_census.py $trace $OUT/${TAG}_1trial_gap_census --iters 60 --skip-tail 45 --label "1 trial, round 5 HEAD" | head -20
 }
+trace_bench_eager() {  # the launch mode bench.py's event-timed roofline iterations run in (a replayed graph cannot carry event pairs)
+  prof 400 bench_eager "" $B --steps 100 --warmup 20 --no-graph --cpu-baseline-iters 0 --gpu-torch-baseline-iters 0 --no-parity --no-span-timing --no-hbm-resident --no-dry-collective
+}
 trace5()   { prof 400 config5_bert_tag "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 5; }
 trace3()   { prof 400 config3_resnet50_seethrough "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 3; }
 trace_fedavg() {
