@@ -43,7 +43,7 @@ bench_n1()     { timeout 600 $B > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench
 bench_4()      { timeout 600 $B --trials-per-gpu 4 --cpu-baseline-iters 0 --no-hbm-resident > $OUT/${TAG}_bench_n1_4trials_in_flight.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_n1_4trials_in_flight.json; }
 bench_8ranks() { timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 20 --warmup 5 > $OUT/${TAG}_bench_8ranks_one_gpu.json 2> $OUT/${TAG}_bench_8ranks_one_gpu.err; tail -1 $OUT/${TAG}_bench_8ranks_one_gpu.json | cut -c1-900; tail -3 $OUT/${TAG}_bench_8ranks_one_gpu.err | cut -c1-300; }
 trace_bench()  {
-  prof 400 bench "" $B --steps 100 --warmup 20 --cpu-baseline-iters 0 --no-span-timing --no-hbm-resident --no-dry-collective
+  prof 400 bench "" $B --steps 100 --warmup 20 --cpu-baseline-iters 0 --gpu-torch-baseline-iters 0 --no-parity --no-span-timing --no-hbm-resident --no-dry-collective
   trace=$(ls -S $(find /tmp/prof_${TAG}_bench -name "*kernel_trace.csv") | head -1)
   [ -n "$trace" ] && python scripts/gap_census.py $trace $OUT/${TAG}_1trial_gap_census --iters 60 --skip-tail 45 --label "1 trial, round 5 HEAD" | head -20
 }
@@ -65,7 +65,7 @@ pmc_resnet50() { pmc resnet50; }
 pmc_resnet18() { pmc resnet18; }
 pmc_mt()       { pmc mt_resnet50; pmc mt_bert; }
 cfg24k()   { timeout 900 python scripts/config_runs.py --only 24k --starts 8 > $OUT/${TAG}_config1_24k_8starts.log 2>&1; tail -1 $OUT/${TAG}_config1_24k_8starts.log > $OUT/${TAG}_config1_24k_8starts.json; grep "hip .* reference" $OUT/${TAG}_config1_24k_8starts.log | cut -c1-250; }
-configs()  { timeout 1500 python scripts/config_runs.py > $OUT/${TAG}_config_runs_same_process.log 2>&1; tail -12 $OUT/${TAG}_config_runs_same_process.log | cut -c1-400; }
+configs()  { timeout 1500 python scripts/config_runs.py --full --its 1000 > $OUT/${TAG}_config_runs_same_process.log 2>&1; tail -12 $OUT/${TAG}_config_runs_same_process.log | cut -c1-400; }
 control()  { timeout 900 python tests/control_same_gpu_torch.py --out $OUT/${TAG}_control_same_gpu_torch.json > $OUT/${TAG}_control_same_gpu_torch.log 2>&1; tail -14 $OUT/${TAG}_control_same_gpu_torch.log | cut -c1-260; }
 torch24()  { timeout 900 python tests/control_same_gpu_torch.py --torch-only --first-start 8 --starts 24 --processes 3 --out $OUT/${TAG}_torch_on_gpu_24_more_starts.json > $OUT/${TAG}_torch_on_gpu_24_more_starts.log 2>&1; tail -10 $OUT/${TAG}_torch_on_gpu_24_more_starts.log | cut -c1-200; }
 tagtwin()  { timeout 600 python scripts/tag_twin_probe.py > $OUT/${TAG}_tag_twin_probe.jsonl 2> $OUT/${TAG}_tag_twin_probe.err; cut -c1-600 $OUT/${TAG}_tag_twin_probe.jsonl; tail -2 $OUT/${TAG}_tag_twin_probe.err | cut -c1-200; }
