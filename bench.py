@@ -20,6 +20,8 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     `roofline.hbm_resident`: the same kernels timed in the same run on a synthetic list of BERT-base's 201 gradient tensors
     (86.07 M elements, 688.6 MB per forward launch -- 2.7x the 256 MiB Infinity Cache, so this is an HBM figure, which the
     ResNet-18 list's is not).
+    `roofline.traffic`: HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, separate passes) collected IN THIS
+    RUN, after the timed region, over scripts/pmc_target.py (N = 1; the committed passes are the fall-back, `traffic_source` says which).
     `roofline.ceiling`: what a launch shaped like kernel A's forward (same persistent grid, same eight staged 16-byte loads
     per lane, two multiply-adds per element instead of the objective; scripts/diag/read_ceiling.hip, NOT part of the library)
     reaches on buffers of the same size in this run, right behind a writer -- for a list that streams from the 256 MiB
@@ -74,6 +76,53 @@ def pmc_traffic_bytes(kernel, sources=None):
                         sources.append(os.path.basename(paths[-1]))
                     break
     return int(total) if found == 2 else None
+
+
+def pmc_traffic_live(size="resnet18", timeout=150):
+    """HBM bytes per launch of kernel A, collected NOW: two bounded subprocesses, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
+    (separate passes, counters only -- no tracing in the same run, as MI355X_MICROARCH.md's HBM section prescribes), over
+    scripts/pmc_target.py: kernel A forward / finalize / backward alone on a synthetic list of this workload's size (under the full
+    attack loop rocprofv3's counter collection segfaults inside torch's convolution on this image).  Returns
+    {"gm_fwd_kernel": bytes, "gm_bwd_kernel": bytes} (FETCH_SIZE x 2 -- the gfx950 half-count of wide coalesced reads -- plus
+    WRITE_SIZE, values in KiB) or None when rocprofv3 is absent or a pass fails; the caller then falls back to the committed passes."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            cmd = [rocprof, "--pmc", counter, "--output-format", "csv", "-d", tmp, "--", sys.executable,
+                   os.path.join(ROOT, "scripts", "pmc_target.py"), "--size", size, "--reps", "4"]
+            proc = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, capture_output=True, text=True, timeout=timeout)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if proc.returncode != 0 or not files:
+                return None
+            sums = {}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    for key in ("gm_fwd_kernel", "gm_bwd_kernel"):
+                        if key in row["Kernel_Name"]:
+                            sums.setdefault(key, []).append(float(row["Counter_Value"]))
+            for key, values in sums.items():
+                per.setdefault(key, {})[counter] = sum(values) / len(values)
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for key, c in per.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            out[key] = int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0)
+    return out or None
 
 
 def committed_replay_duration(kernel_prefix):
@@ -364,6 +413,9 @@ def parse_args():
                    help="force kernel A's cache policy (0 auto / 1 plain / 2 non-temporal loads / 3 + non-temporal stores), forward[,backward]")
     p.add_argument("--gpu-torch-baseline-iters", type=int, default=60,
                    help="timed iterations of the PyTorch-ROCm port of the attack on the same GPU (0 disables); N = 1 only")
+    p.add_argument("--no-live-pmc", action="store_true",
+                   help="take roofline.traffic from the committed rocprofv3 --pmc passes instead of collecting it in this run (two bounded "
+                        "rocprofv3 subprocesses over scripts/pmc_target.py after the timed region, ~30 s; N = 1 only)")
     p.add_argument("--no-parity", action="store_true", help="skip the teacher-forced parity evaluation against the reference fixture")
     p.add_argument("--no-hbm-resident", action="store_true", help="skip the BERT-base sized kernel-A timing (roofline.hbm_resident)")
     p.add_argument("--model", default="resnet18")
@@ -632,8 +684,16 @@ def main():
                 roofline["frac_of_ceiling"] = round(roofline["ceiling"]["us"] / kernels["fwd"]["avg_us"], 4)
         except Exception as exc:  # the diagnostic library is not part of the product: its absence never fails the bench
             roofline["ceiling"] = dict(error=repr(exc)[:300])
+    live = None
+    if roofline is not None and rank == 0 and world == 1 and not args.no_live_pmc and not args.no_kernel_timing and args.model in ("resnet18", "resnet50"):
+        live = pmc_traffic_live(args.model)
+        if live and "gm_fwd_kernel" in live:
+            roofline["traffic"] = live["gm_fwd_kernel"]
+            roofline["traffic_source"] = ("collected in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate bounded passes over "
+                                          "scripts/pmc_target.py (kernel A alone at this list size), FETCH_SIZE x 2 + WRITE_SIZE")
+            roofline["traffic_over_algorithmic"] = round(live["gm_fwd_kernel"] / fwd_bytes, 4)
     if "bwd" in kernels:
-        kernels["bwd"]["traffic"] = pmc_traffic_bytes("gm_bwd_kernel")
+        kernels["bwd"]["traffic"] = live["gm_bwd_kernel"] if live and "gm_bwd_kernel" in live else pmc_traffic_bytes("gm_bwd_kernel")
         kernels["bwd"]["frac_of_hbm_peak"] = round(kernels["bwd"]["achieved_GBs"] / HBM_PEAK_GBS, 4)
 
     # ---- trial selection: the one collective of the multi-GPU path --------------------------------------------------
