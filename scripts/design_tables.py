@@ -136,7 +136,8 @@ def build():
         if fk in eager and fk in replay:
             L.append(f"| the same two kernels by rocprofv3, by launch mode: `bench.py --no-graph` (eager launches -- the mode the event-timed iterations above run in, a replayed graph cannot carry event pairs; `r5_bench_eager_kernel_summary.txt`) / inside graph replay (`r5_bench_kernel_summary.txt`) | forward {eager[fk][1]:.2f} / {replay[fk][1]:.2f} us = {_frac(r['algorithmic_bytes'], eager[fk][1]):.3f} / **{_frac(r['algorithmic_bytes'], replay[fk][1]):.3f}**; backward {eager[bk][1]:.2f} / {replay[bk][1]:.2f} us = {_frac(k['bwd']['algorithmic_bytes'], eager[bk][1]):.3f} / **{_frac(k['bwd']['algorithmic_bytes'], replay[bk][1]):.3f}** -- events and rocprofv3 agree within {abs(eager[fk][1] / r['avg_launch_us'] - 1) * 100:.0f} % in the same launch mode; inside the replayed graph (the timed region) the kernels are {(1 - replay[fk][1] / eager[fk][1]) * 100:.0f} % faster |")
         if r.get("traffic") and k["bwd"].get("traffic"):
-            L.append(f"| PMC traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE; committed passes at HEAD), forward / backward | {r['traffic'] / 1e6:.2f} MB vs {r['algorithmic_bytes'] / 1e6:.2f} MB (**{r['traffic'] / r['algorithmic_bytes']:.3f}**) / {k['bwd']['traffic'] / 1e6:.2f} vs {k['bwd']['algorithmic_bytes'] / 1e6:.2f} MB (**{k['bwd']['traffic'] / k['bwd']['algorithmic_bytes']:.3f}**) |")
+            how = "collected by the bench itself in this run" if str(r.get("traffic_source", "")).startswith("collected in this run") else "committed passes at HEAD"
+            L.append(f"| PMC traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes; {how}), forward / backward | {r['traffic'] / 1e6:.2f} MB vs {r['algorithmic_bytes'] / 1e6:.2f} MB (**{r['traffic'] / r['algorithmic_bytes']:.3f}**) / {k['bwd']['traffic'] / 1e6:.2f} vs {k['bwd']['algorithmic_bytes'] / 1e6:.2f} MB (**{k['bwd']['traffic'] / k['bwd']['algorithmic_bytes']:.3f}**) |")
         h = r.get("hbm_resident") or {}
         for kind in ("cosine-similarity", "tag-euclidean"):
             if kind in h:
