@@ -197,6 +197,18 @@ def build():
         L += ["**The ceiling kernel A's forward is priced against** (`r5_read_ceiling_probe.jsonl`; `diag_read` = kernel A's persistent grid of 512 workgroups and eight staged 16-byte loads per lane over two buffers, two multiply-adds per element, outside the library; all columns: dispatch start/stop events, median of 30, us):", "",
               "| list | bare read warm: plain / non-temporal loads | bare read behind a writer: plain / nt | kernel A forward warm | kernel A forward behind a writer (same bytes as ONE tensor: full chunks only) | best bare read / kernel A, behind a writer (warm) |", "|---|---|---|---|---|---|"] + rows + [""]
 
+    rows = []
+    for lst in ("resnet18", "resnet50", "bert_base"):
+        rw = next((p for p in probe if p.get("list") == lst and p.get("kernel", "").startswith("diag_rw")), None)
+        kb = next((p for p in probe if p.get("list") == lst and p.get("kernel", "").startswith("kernel A backward")), None)
+        if rw and kb:
+            best = min(v for k, v in rw.items() if k.endswith("_us") and v)
+            rows.append(f"| {lst} ({kb['bytes'] / 1e6:.1f} MB) | {rw['plain_warm_us']} / {rw['plain_behind_writer_us']} | {rw['nt_loads_warm_us']} / {rw['nt_loads_behind_writer_us']} | "
+                        f"{rw['nt_loads_and_stores_warm_us']} / {rw['nt_loads_and_stores_behind_writer_us']} | {kb['us']} ({kb['frac_of_8TBps']:.2f} of 8 TB/s) | **{best / kb['us']:.2f}** |")
+    if rows:
+        L += ["The same for the read-two-write-one shape of kernel A's backward and the multi-tensor kernels (`diag_rw`: one workgroup per chunk, four staged 16-byte loads per lane and buffer, 16-byte stores; warm / behind a writer, us):", "",
+              "| list | plain | non-temporal loads | non-temporal loads and stores | kernel A backward right after its forward | best bare launch / kernel A backward |", "|---|---|---|---|---|---|"] + rows + [""]
+
     # --- multi-tensor kernels
     rows = []
     sa = _by_grid("r5_mt_kernel_probe_kernel_by_grid.csv")

@@ -39,6 +39,27 @@ __global__ __launch_bounds__(kBlock) void diag_read_kernel(const float* __restri
   if (acc == 123456.789f) out[blockIdx.x] = acc;  // keeps the loads alive; practically never taken
 }
 
+// The backward / multi-tensor shape reduced to its memory side: one workgroup per chunk (as gm_bwd_kernel and mt_kernel launch),
+// four staged 16-byte loads per lane and buffer, out = a + 0.5 b, 16-byte stores (plain or non-temporal).
+template <bool NTL, bool NTS>
+__global__ __launch_bounds__(kBlock) void diag_rw_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o) {
+  const int64_t c = blockIdx.x;
+  const v4f* a4 = reinterpret_cast<const v4f*>(a + c * kChunk);
+  const v4f* b4 = reinterpret_cast<const v4f*>(b + c * kChunk);
+  v4f* o4 = reinterpret_cast<v4f*>(o + c * kChunk);
+  v4f av[kVec], bv[kVec];
+#pragma unroll
+  for (int k = 0; k < kVec; ++k) av[k] = load16<NTL>(a4 + threadIdx.x + k * kBlock);
+#pragma unroll
+  for (int k = 0; k < kVec; ++k) bv[k] = load16<NTL>(b4 + threadIdx.x + k * kBlock);
+#pragma unroll
+  for (int k = 0; k < kVec; ++k) {
+    const v4f r = av[k] + 0.5f * bv[k];
+    if constexpr (NTS) __builtin_nontemporal_store(r, o4 + threadIdx.x + k * kBlock);
+    else o4[threadIdx.x + k * kBlock] = r;
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void diag_fill_kernel(float* __restrict__ p, int64_t n4, float value) {
   v4f v;
   v.x = v.y = v.z = v.w = value;
@@ -82,7 +103,35 @@ int diag_read_timed(const float* a, const float* b, int64_t n_chunks, int32_t gr
     if (hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]) != hipSuccess) rc = rc ? rc : -4;
     us_out[r] = ms * 1e3f;
   }
-  for (int i = 0; i < 2 * reps; ++i) hipEventDestroy(ev[i]);
+  for (int i = 0; i < 2 * reps; ++i) (void)hipEventDestroy(ev[i]);
+  return rc;
+}
+
+// `reps` launches of diag_rw (read a, b; write o; n_chunks workgroups), dispatch start / stop events; policy 0 plain, 1 non-temporal
+// loads, 2 non-temporal loads and stores (kernel A's BH_GM_CACHE_KEEP / _STREAM / _STREAM_ALL); optionally each behind a diag_fill of `a`.
+int diag_rw_timed(const float* a, const float* b, float* o, int64_t n_chunks, int32_t policy, void* stream, int32_t fill_first, int32_t reps,
+                  float* us_out) {
+  if (a == nullptr || b == nullptr || o == nullptr || us_out == nullptr || n_chunks <= 0 || reps <= 0 || reps > 1024) return -1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipEvent_t ev[2048];
+  for (int i = 0; i < 2 * reps; ++i)
+    if (hipEventCreate(&ev[i]) != hipSuccess) return -2;
+  const dim3 grid((unsigned)n_chunks), block(kBlock);
+  for (int r = 0; r < reps; ++r) {
+    if (fill_first)
+      hipLaunchKernelGGL(diag_fill_kernel, dim3(2048), dim3(kBlock), 0, st, const_cast<float*>(a), (n_chunks * kChunk) >> 2, 0.5f);
+    if (policy == 2) hipExtLaunchKernelGGL((diag_rw_kernel<true, true>), grid, block, 0, st, ev[2 * r], ev[2 * r + 1], 0, a, b, o);
+    else if (policy == 1) hipExtLaunchKernelGGL((diag_rw_kernel<true, false>), grid, block, 0, st, ev[2 * r], ev[2 * r + 1], 0, a, b, o);
+    else hipExtLaunchKernelGGL((diag_rw_kernel<false, false>), grid, block, 0, st, ev[2 * r], ev[2 * r + 1], 0, a, b, o);
+  }
+  int rc = -(int)hipGetLastError();
+  if (hipStreamSynchronize(st) != hipSuccess) rc = rc ? rc : -3;
+  for (int r = 0; r < reps; ++r) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[2 * r], ev[2 * r + 1]) != hipSuccess) rc = rc ? rc : -4;
+    us_out[r] = ms * 1e3f;
+  }
+  for (int i = 0; i < 2 * reps; ++i) (void)hipEventDestroy(ev[i]);
   return rc;
 }
 

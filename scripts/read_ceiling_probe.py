@@ -144,7 +144,35 @@ def main():
                 t = sorted(us)
                 row[f"{'nt_' if nt else ''}{tag}_us"] = round(t[len(t) // 2], 2) if rc == 0 else None
         print(json.dumps(row), flush=True)
-        del a, b
+        # the backward / multi-tensor shape: read two buffers, write one (3 N 4 bytes), one workgroup per chunk -- next to kernel A's
+        # own backward on the model's list (plan.backward after plan.forward; events of the C side)
+        diag.diag_rw_timed.restype = _ct.c_int
+        diag.diag_rw_timed.argtypes = [_ct.c_void_p, _ct.c_void_p, _ct.c_void_p, _ct.c_int64, _ct.c_int32, _ct.c_void_p, _ct.c_int32, _ct.c_int32,
+                                       _ct.POINTER(_ct.c_float)]
+        o = torch.empty_like(a)
+        row = dict(list=name, kernel="diag_rw (read a, b; write o), dispatch start/stop events", bytes=3 * n_chunks * CHUNK * 4, workgroups=n_chunks)
+        for policy, tag in ((0, "plain"), (1, "nt_loads"), (2, "nt_loads_and_stores")):
+            for cond, fill in (("warm", 0), ("behind_writer", 1)):
+                us = (_ct.c_float * args.launches)()
+                rc = diag.diag_rw_timed(a.data_ptr(), b.data_ptr(), o.data_ptr(), n_chunks, policy, stream, fill, args.launches, us)
+                t = sorted(us)
+                row[f"{tag}_{cond}_us"] = round(t[len(t) // 2], 2) if rc == 0 else None
+        print(json.dumps(row), flush=True)
+        gen = torch.Generator(device=device).manual_seed(2)
+        data = [torch.randn(s, device=device, generator=gen) for s in shapes]
+        rec = [torch.randn(s, device=device, generator=gen) for s in shapes]
+        plan = GradientMatchPlan(data)
+        row = dict(list=name, kernel="kernel A backward (cosine), model list, after its forward", bytes=3 * n * 4, chunks=plan.n_chunks)
+        for _ in range(3):
+            plan.backward(0, rec, plan.forward(0, rec, 1.0, 0.0, 1e-7, None), None, None)
+        plan.enable_timing()
+        for _ in range(args.launches):
+            plan.backward(0, rec, plan.forward(0, rec, 1.0, 0.0, 1e-7, None), None, None)
+        torch.cuda.synchronize(device)
+        t = sorted(plan.drain_timers()["bwd"])
+        row["us"], row["best_us"], row["frac_of_8TBps"] = round(t[len(t) // 2], 2), round(t[0], 2), round(3 * n * 4 / (t[len(t) // 2] * 1e-6) / PEAK, 3)
+        print(json.dumps(row), flush=True)
+        del a, b, o, data, rec, plan
         torch.cuda.empty_cache()
 
 
