@@ -25,6 +25,9 @@
 extern "C" {
 #endif
 
+/* 6: multi-tensor launch groups are BH_MT_MAX_PTRS = 112 tensors (two adjacent groups per launch for the forms with at most two
+ *    pointer lists), bh_mt_* write outputs larger than the Infinity Cache with non-temporal stores; 5: tuning knobs became launch
+ *    arguments (no mutable library state). */
 #define BH_ABI_VERSION 6
 #define BH_EINVAL (-1)
 
