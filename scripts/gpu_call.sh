@@ -27,6 +27,7 @@ prof() {  # prof <seconds> <name> <pmc-counter or ""> <command...>: rocprofv3 ke
   tail -1 $OUT/${name}_stdout.log | cut -c1-300
 }
 
+example()  { timeout 300 python examples/minimal_example.py > $OUT/${TAG}_minimal_example.log 2>&1; tail -2 $OUT/${TAG}_minimal_example.log | cut -c1-300; }
 smoke()    { timeout 300 python __graft_entry__.py smoke > $OUT/${TAG}_smoke.log 2>&1; tail -1 $OUT/${TAG}_smoke.log | cut -c1-200; }
 kernels()  { timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q > $OUT/${TAG}_gpu_tests_kernels.log 2>&1; tail -3 $OUT/${TAG}_gpu_tests_kernels.log | cut -c1-250; }
 newtests() { timeout 900 python -m pytest tests -m gpu -x -q -s -k "$NEWTESTS" > $OUT/${TAG}_gpu_tests_new.log 2>&1; tail -4 $OUT/${TAG}_gpu_tests_new.log | cut -c1-300; }
