@@ -167,3 +167,34 @@ def test_side_streams_fall_back_to_pool_streams_when_the_calibration_cannot_run(
         assert ("failed" in report) == (failure == "raises")
         assert [a.cuda_stream for a in streams.side_streams(dev, 3)] == [s.cuda_stream for s in chosen[:3]]  # cached like a measured choice
     streams._CHOSEN.clear()
+
+
+def test_bench_line_contract():
+    """`python bench.py` (the driver's entry point) as a subprocess with small counts: ONE JSON line on stdout with the contract's
+    fields -- BASELINE.json's metric, value = K steps / measured time, n_gpus, dtype of the arithmetic, a workload-naming config --
+    and the legs this repository adds to it: `roofline` (HBM bound, frac = achieved / peak, algorithmic bytes of kernel A's forward,
+    a measured read `ceiling`), `parity` (teacher-forced evaluation against the reference fixture, ok), `gpu_torch_baseline` (the port
+    on the same GPU, slower than the HIP path), `cpu_baseline`."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-baseline-iters", "2",
+           "--gpu-torch-baseline-iters", "4", "--roofline-steps", "6", "--no-live-pmc", "--no-hbm-resident", "--no-dry-collective"]
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, proc.stdout[-1000:]
+    line = json.loads(lines[0])
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        assert line["metric"] == json.load(f)["metric"]
+    assert line["unit"] == "attack iterations/s" and line["n_gpus"] == 1 and line["steps"] == 6 and line["higher_is_better"] is True
+    assert line["dtype"] == "f32" and line["data"] == "synthetic" and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and "resnet18" in line["config"]["workload"] and "model" not in line["config"]
+    assert line["value"] == pytest.approx(6 / (line["ms_per_step"] * 6e-3), rel=1e-3) and line["launch_mode"] == "hipGraph replay"
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and roof["algorithmic_bytes"] == 2 * 11_689_512 * 4
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3) and 0.3 < roof["frac"] < 1.0
+    assert roof["traffic"] is None or 0.99 < roof["traffic"] / roof["algorithmic_bytes"] < 1.02
+    assert 5.0 < roof["ceiling"]["us"] < 40.0 and 0.5 < roof["frac_of_ceiling"] <= 1.1
+    parity = line["parity"]
+    assert parity["ok"] is True and parity["iterate"] > 23_000 and parity["loss_rel_err"] <= parity["loss_tolerance"]
+    assert parity["sign_agreement"] > 0.99 > parity["reference_twin_agreement"] > 0.9
+    assert 0 < line["gpu_torch_baseline"]["value"] < line["value"]
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] in ("reference", "port")
