@@ -145,6 +145,19 @@ def committed_replay_duration(kernel_prefix):
     return None, None
 
 
+def device_record(device):
+    """Which GPU and software produced the line (box-to-box differences of a few per cent come with MIOpen's timing-based solver
+    choice on a fresh box and with the board; this is what a reader needs to tell two lines apart)."""
+    import torch
+
+    try:
+        props = torch.cuda.get_device_properties(device)
+        return dict(name=props.name, arch=getattr(props, "gcnArchName", None), compute_units=props.multi_processor_count,
+                    memory_GB=round(props.total_memory / 1e9, 1), torch=torch.__version__, hip=getattr(torch.version, "hip", None))
+    except Exception as exc:  # provenance only: never fatal
+        return dict(error=repr(exc)[:200])
+
+
 def bert_base_gradient_shapes():
     """The 201 gradient tensors a TAG attack on BERT-base (MLM head, vocabulary 30 522) matches: every parameter but the
     word-embedding matrix (base_attack.py:94 pops it).  86 073 402 elements (SURVEY.md section 8 size table)."""
@@ -781,6 +794,7 @@ def main():
             "rccl_dry_run": rccl_dry_run,
             "collective_backend": backend if world > 1 else None,
             "oversubscribed": bool(oversubscribed),
+            "device": device_record(device),
             "staged_start": None if world == 1 else "rank 0 warms up first; ranks > 0 start from a copy of its MIOpen find-db",
         }
         print(json.dumps(line), flush=True)
