@@ -198,3 +198,37 @@ def test_bench_line_contract():
     assert parity["sign_agreement"] > 0.99 > parity["reference_twin_agreement"] > 0.9
     assert 0 < line["gpu_torch_baseline"]["value"] < line["value"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] in ("reference", "port")
+
+
+def test_graph_capture_with_a_live_rccl_process_group():
+    """What every rank of the multi-GPU path does and a 1-GPU box had never done IN ONE PROCESS: capture the attack iteration into a
+    hipGraph while an RCCL ("nccl") process group is alive -- its watchdog thread polls events in the background, which a capture in
+    the default `global` error mode can take for an illegal call and abort (the run would then fall back to eager launches, 2.4x
+    slower, on every rank of the driver's scaling run).  One-rank communicator on cuda:0, one all-reduce to start the machinery, then
+    a ConvNet attack with hip_graph="required" and a collective after it."""
+    code = r"""
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+import breaching_amd
+from breaching_amd.cases import build_case, initial_candidate
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[1])
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+t = torch.ones(4, device=dev); dist.all_reduce(t); torch.cuda.synchronize()
+case = build_case("convnet", "CIFAR10", 1, device=dev)
+cfg = breaching_amd.get_attack_config("invertinggradients", ["optim.max_iterations=12", "optim.callback=6", "impl.hip_graph=required"])
+attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, dict(device=dev, dtype=torch.float))
+os.environ["BREACH_HIP_TRIAL_DEVICES"] = "0"
+rec, stats = attacker.reconstruct(case.server_payload, case.shared_data, {}, initial_data=initial_candidate(case.data_cfg, 1, seed=6))
+dist.all_reduce(t); torch.cuda.synchronize()
+print(json.dumps(dict(execution=sorted(set(stats["execution"]["trials"].values())), losses=len(stats["Trial_0_Val"]), t=float(t[0]))))
+dist.destroy_process_group()
+"""
+    from breaching_amd.workers import free_port
+
+    proc = subprocess.run([sys.executable, "-c", code, str(free_port())], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["execution"] == ["hipGraph replay"] and rec["losses"] == 12 and rec["t"] == 1.0
