@@ -237,10 +237,10 @@ def build():
     if rows:
         L += ["**Multi-tensor kernels (SURVEY section 8 f2 / f3)** -- rocprofv3 dispatch durations, fraction of 8 TB/s on algorithmic bytes (3 N 4 / 2 N 4 / 4 N 4):", "",
               "| form | list | launches per call | us per call | of peak | where |", "|---|---|---|---|---|---|"] + rows + [""]
-        pr = {lst: _pmc_ratio(f"r5_pmc_fetch_mt_{t}_pmc_summary.csv", f"r5_pmc_write_mt_{t}_pmc_summary.csv", "mt_kernel<0", 3 * N_LIST[lst] * 4, 2)
+        pr = {lst: _pmc_ratio(f"r5_pmc_fetch_mt_{t}_pmc_summary.csv", f"r5_pmc_write_mt_{t}_pmc_summary.csv", "mt_kernel<0", 3 * N_LIST[lst] * 4, 1)
               for lst, t in (("resnet50", "resnet50"), ("bert_base", "bert"))}
         if all(pr.values()):
-            L += [f"PMC traffic of `a + alpha b` per call (taken before the single-launch change, two dispatches per call; `r5_pmc_{{fetch,write}}_mt_{{resnet50,bert}}_pmc_summary.csv`): "
+            L += [f"PMC traffic of `a + alpha b` per call (one dispatch per call; non-temporal stores at BERT size; `r5_pmc_{{fetch,write}}_mt_{{resnet50,bert}}_pmc_summary.csv`): "
                   f"ResNet-50 {pr['resnet50'][0] / 1e6:.1f} MB = {pr['resnet50'][1]:.3f} of the algorithmic bytes, BERT-base {pr['bert_base'][0] / 1e6:.1f} MB = {pr['bert_base'][1]:.3f}.", ""]
 
     # --- kernels B and C
