@@ -152,8 +152,21 @@ def device_record(device):
 
     try:
         props = torch.cuda.get_device_properties(device)
-        return dict(name=props.name, arch=getattr(props, "gcnArchName", None), compute_units=props.multi_processor_count,
-                    memory_GB=round(props.total_memory / 1e9, 1), torch=torch.__version__, hip=getattr(torch.version, "hip", None))
+        record = dict(name=props.name, arch=getattr(props, "gcnArchName", None), compute_units=props.multi_processor_count,
+                      memory_GB=round(props.total_memory / 1e9, 1), torch=torch.__version__, hip=getattr(torch.version, "hip", None))
+        try:  # current clock levels, when rocm-smi is there: the first thing to look at when two boxes differ by a few per cent
+            import shutil
+            import subprocess
+
+            smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+            out = subprocess.run([smi, "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+            if out.returncode == 0 and out.stdout.strip().startswith("{"):
+                cards = json.loads(out.stdout)
+                card = cards.get(f"card{device.index or 0}") or next(iter(cards.values()))
+                record["clocks"] = {k: v for k, v in card.items() if "clock" in k.lower()}
+        except Exception:
+            pass
+        return record
     except Exception as exc:  # provenance only: never fatal
         return dict(error=repr(exc)[:200])
 
