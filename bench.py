@@ -78,7 +78,7 @@ def pmc_traffic_bytes(kernel, sources=None):
     return int(total) if found == 2 else None
 
 
-def pmc_traffic_live(size="resnet18", timeout=150):
+def pmc_traffic_live(size="resnet18", timeout=90):
     """HBM bytes per launch of kernel A, collected NOW: two bounded subprocesses, `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE`
     (separate passes, counters only -- no tracing in the same run, as MI355X_MICROARCH.md's HBM section prescribes), over
     scripts/pmc_target.py: kernel A forward / finalize / backward alone on a synthetic list of this workload's size (under the full
