@@ -744,3 +744,30 @@ def test_gap_census_on_a_synthetic_trace(tmp_path):
     assert families["ATen: add (accumulation, residual)"]["gap_before_us_per_iter"] == pytest.approx(40.0 + 47.0)  # ... and to its successor
     assert families["ours: kernel B/C, commit (step, tv, loss)"]["calls_per_iter"] == 1.0
     assert os.path.exists(tmp_path / "out_one_iteration.csv")
+
+
+def test_fail_open_policies_parse_config_and_environment(monkeypatch):
+    """The three policies that decide whether an optimisation of ours may stop an attack -- hipGraph capture, the BatchNorm -> ReLU
+    fusion -- default to "auto" (fail open: fall back, say so), turn into "required" only when asked to, and the environment
+    overrides the config (what the test suite uses to make every silent fall-back an error)."""
+    from breaching_amd import get_attack_config
+    from breaching_amd.attacker import graph_replay_policy
+    from breaching_amd.victim_layers import fuse_bn_relu_enabled, fuse_bn_relu_policy
+
+    for var in ("BREACH_HIP_FUSE_BN_RELU", "BREACH_HIP_GRAPH", "BREACH_HIP_GRAPH_STRICT"):
+        monkeypatch.delenv(var, raising=False)
+    base = get_attack_config("invertinggradients")
+    assert fuse_bn_relu_policy(base) == "auto" and fuse_bn_relu_policy(None) == "auto" and graph_replay_policy(base) == "auto"
+    for value, want in ((True, "auto"), ("auto", "auto"), ("required", "required"), (False, "off"), ("0", "off"), (None, "auto")):
+        cfg = get_attack_config("invertinggradients", [f"impl.fuse_bn_relu={value}"])
+        assert fuse_bn_relu_policy(cfg) == want, (value, fuse_bn_relu_policy(cfg))
+        assert fuse_bn_relu_enabled(cfg) == (want != "off")
+        cfg = get_attack_config("invertinggradients", [f"impl.hip_graph={value}"])
+        assert graph_replay_policy(cfg) == want, (value, graph_replay_policy(cfg))
+    monkeypatch.setenv("BREACH_HIP_FUSE_BN_RELU", "required")
+    assert fuse_bn_relu_policy(get_attack_config("invertinggradients", ["impl.fuse_bn_relu=False"])) == "required"
+    monkeypatch.setenv("BREACH_HIP_FUSE_BN_RELU", "0")
+    assert fuse_bn_relu_policy(base) == "off"
+    monkeypatch.setenv("BREACH_HIP_GRAPH_STRICT", "1")  # tests/conftest.py: every "auto" becomes "required", "off" stays off
+    assert graph_replay_policy(base) == "required"
+    assert graph_replay_policy(get_attack_config("invertinggradients", ["impl.hip_graph=False"])) == "off"
