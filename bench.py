@@ -310,9 +310,34 @@ def parity_leg(device, model_name):
     same = (torch.sign(g) == sign_ref).double()
     want = float(gold["history"][k])
     ref_psnr = np.concatenate([[gold["psnr"]], gold["twin_psnr"]])
+    # The same-arithmetic control: the SAME evaluation at the same iterate on the same GPU with PyTorch-ROCm ops throughout --
+    # oracle/restate.py's statements (the checker, pinned to the reference by tests/test_oracle_pinning.py), torch's own BatchNorm,
+    # no kernel of libbreach_hip.so.  Its deviation from the CPU reference is MIOpen-vs-oneDNN in the victim's convolutions at a
+    # kink-dense late iterate; what the HIP path adds on top is |hip - control|.  The gate is 3x the control's own deviation
+    # (never below north_star's 1e-4), not a multiple of the recorded kink sensitivity.
+    import copy
+
+    from oracle import restate
+
+    control_model = copy.deepcopy(case.model).to(device).eval()
+    xc = torch.as_tensor(gold["forced_x"][i]).to(device).clone().requires_grad_(True)
+    task = case.loss_fn(control_model(xc), labels)
+    rec_grads = torch.autograd.grad(task, tuple(control_model.parameters()), create_graph=True)
+    control_total = restate.gradient_objective("cosine-similarity", rec_grads, [g.to(device) for g in case.shared_data[0]["gradients"]], cfg.objective)
+    control_total = control_total + restate.total_variation(xc, **cfg.regularization["total_variation"])
+    (gc,) = torch.autograd.grad(control_total, [xc])
+    control_same = (torch.sign(gc.detach().cpu()) == sign_ref).double()
+    control_rel = abs(float(control_total) - want) / want
     out = dict(fixture="tests/golden/attack_resnet18_24k.npz (unmodified reference on CPU, 24 000 iterations)", iterate=k,
                loss_reference=want, loss_hip=float(total), loss_rel_err=abs(float(total) - want) / want,
-               loss_tolerance=max(1e-4, 10.0 * float(gold["forced_sensitivity"][i])),
+               loss_tolerance=max(1e-4, 3.0 * control_rel),
+               control=dict(what="the same evaluation on this GPU with PyTorch-ROCm ops only (oracle/restate.py statements, torch BatchNorm): "
+                                 "same victim convolutions as the HIP path, no kernel of libbreach_hip.so",
+                            loss=float(control_total), loss_rel_err=control_rel, sign_agreement=float(control_same.mean()),
+                            weighted_sign_agreement=float((control_same * weight).sum() / weight.sum()),
+                            sign_agreement_hip_vs_control=float((torch.sign(g) == torch.sign(gc.detach().cpu())).double().mean())),
+               loss_hip_vs_control_rel=abs(float(total) - float(control_total)) / abs(float(control_total)),
+               kink_sensitivity_recorded=float(gold["forced_sensitivity"][i]),
                sign_agreement=float(same.mean()), reference_twin_agreement=float(gold["forced_twin_sign_agreement"][i]),
                weighted_sign_agreement=float((same * weight).sum() / weight.sum()),
                reference_twin_weighted_agreement=float(gold["forced_twin_weighted_sign_agreement"][i]),
@@ -324,7 +349,8 @@ def parity_leg(device, model_name):
         try:
             with open(hip_runs) as f:
                 rec = json.load(f)
-            out["psnr_db_hip_runs"] = dict(mean=round(float(np.mean(rec["hip"]["psnr_db"])), 4), n=len(rec["hip"]["psnr_db"]), file="profiles/r5_config1_24k_8starts.json")
+            out["from_committed_profiles"] = dict(psnr_db_hip_runs=dict(mean=round(float(np.mean(rec["hip"]["psnr_db"])), 4), n=len(rec["hip"]["psnr_db"]),
+                                                                         file="profiles/r5_config1_24k_8starts.json", note="not measured in this run"))
         except Exception:
             pass
     return out
@@ -426,6 +452,117 @@ def cpu_baseline_leg(model_name, iters, cpu_threads=0):
     return out
 
 
+def restarts32_leg(device, model_name, iters, num_trials=32, pool_world=0, committed_one_gpu=True):
+    """BASELINE configs[3] through the PRODUCT entry: `attacker.reconstruct(server_payload, shared_data)` with restarts.num_trials
+    = 32 on the headline workload -- the loop being sharded is optimization_based_attack.py:70-78, scoring :191-204, selection
+    :206-218 -- wall seconds of the whole call incl. rescoring every trial and the selection.  Horizon shortened to `iters`
+    iterations per trial (the step-lr milestones scale with it; stated in the record).  Two shapes, one function:
+      * `pool_world` <= 1: one process, one GPU: 32 / 4 = 8 groups of four trials in flight (the one-GPU denominator of the 6x claim);
+      * `pool_world` > 1: the single-process entry on a node -- this process is rank 0 and starts a `TrialWorkerPool` of pool_world - 1
+        worker processes ("nccl" = RCCL over xGMI when every rank has its own GPU, gloo when ranks share one: `oversubscribed`),
+        ships the inputs by broadcast, runs its own share four in flight, waits, selects with one all-reduce(MIN) + one broadcast:
+        what `simulate_breach.py` gets on an 8-GPU node without changing a line.  Needs a process without a process group.
+    A `dryrun=True` call (one iteration per trial) comes first in both shapes: pool start, MIOpen solver look-ups and the stream
+    calibration stay out of the timed call and are reported beside it."""
+    import torch
+
+    import breaching_amd
+    from breaching_amd.cases import build_case, psnr
+
+    overrides = [f"restarts.num_trials={num_trials}", f"optim.max_iterations={iters}",
+                 "impl.hip_graph=" + ("required" if pool_world <= 1 else "auto")]
+    oversubscribed = False
+    if pool_world > 1:
+        have = torch.cuda.device_count()
+        oversubscribed = have < pool_world
+        own = device.index or 0
+        devices = [own] + ([i for i in range(have) if i != own][: pool_world - 1] if not oversubscribed else [own] * (pool_world - 1))
+        overrides += [f"impl.trial_devices={devices}", "impl.trial_pool=required"]
+    else:
+        devices = [device.index or 0]  # this process's own GPU only: no pool
+        overrides += [f"impl.trial_devices={devices}"]
+    os.environ["BREACH_HIP_TRIAL_DEVICES"] = ",".join(str(d) for d in devices)  # the environment outranks the config: say it there too
+    cfg = breaching_amd.get_attack_config("invertinggradients", overrides)
+    case = build_case(model_name, "ImageNet", 1, device=device, gradient_device=device)
+    attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, dict(device=device, dtype=torch.float))
+
+    def call(dryrun):
+        shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+        torch.manual_seed(1234)  # the 32 starting points, drawn by rank 0 in the reference's order
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        rec, stats = attacker.reconstruct(case.server_payload, shared, {}, dryrun=dryrun)
+        torch.cuda.synchronize(device)
+        return rec, stats, time.perf_counter() - t0
+
+    try:
+        _, warm_stats, warm_s = call(dryrun=True)
+        rec, stats, wall_s = call(dryrun=False)
+    finally:
+        attacker.close()
+    execution = stats["execution"]
+    ranks = max(pool_world, 1)
+    histories = [stats[f"Trial_{t}_Val"] for t in range(num_trials)]
+    modes = sorted(set(execution["trials"].values()))
+    out = dict(
+        config="BASELINE configs[3]: ResNet-18 ImageNet invertinggradients, restarts.num_trials=32, through attacker.reconstruct()",
+        entry="TrialWorkerPool (single-process entry, workers.py)" if pool_world > 1 else "one process, one GPU",
+        num_trials=num_trials, iterations_per_trial=iters, ranks=ranks, trials_per_rank=-(-num_trials // ranks),
+        trials_in_flight_per_rank=min(4, -(-num_trials // ranks)),
+        horizon_note=f"max_iterations shortened from the shipped 24 000 to {iters} (the step-lr milestones scale with it); every other "
+                     "hyper-parameter as shipped, callback 1000",
+        wall_s=round(wall_s, 3), trial_iterations_per_s=round(num_trials * iters / wall_s, 2),
+        wall_includes="input shipping, prepare_attack, 32 random starts, the trial loops, rescoring every trial (:191-204), selection (:206-218)",
+        timing_rank0=execution["timing"], pool=execution["pool"], pool_fallback=execution["pool_fallback"], oversubscribed=bool(oversubscribed),
+        warmup_call_s=round(warm_s, 3), warmup_call="the same call with dryrun=True (one iteration per trial) first: pool start, MIOpen "
+                                                     "solver look-ups and the stream calibration are paid there, not in wall_s",
+        warmup_pool=warm_stats["execution"]["pool"],
+        launch_modes=modes, histories_complete=bool(all(len(h) == iters for h in histories)),
+        opt_value=stats["opt_value"], winner_final_loss_range=[round(min(h[-1] for h in histories), 6), round(max(h[-1] for h in histories), 6)],
+        psnr_db_selected=round(psnr(rec["data"], case.true_user_data["data"], case.data_cfg), 4),
+    )
+    if ranks > 1 and committed_one_gpu:
+        ref = committed_restarts32_one_gpu(iters, num_trials)
+        if ref is not None:
+            out["from_committed_profiles"] = dict(one_gpu=ref, strong_scaling_vs_one_gpu=round(ref["wall_s"] / wall_s, 3),
+                                                  note="one-GPU wall of the same call from a committed run of this bench on another box (or hour); "
+                                                       "the driver's own N = 1 line of the same round is the denominator proper")
+    return out
+
+
+def committed_restarts32_one_gpu(iters, num_trials):
+    """The newest committed N = 1 line of this bench whose restarts32 leg ran the same horizon (profiles/r*_bench_driver_style*.json)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_driver_style*.json")), reverse=True):
+        try:
+            with open(path) as f:
+                leg = json.loads(f.read().strip().splitlines()[-1]).get("restarts32")
+            if leg and leg.get("ranks") == 1 and leg.get("iterations_per_trial") == iters and leg.get("num_trials") == num_trials:
+                return dict(wall_s=leg["wall_s"], trial_iterations_per_s=leg["trial_iterations_per_s"], file=os.path.basename(path))
+        except Exception:
+            continue
+    return None
+
+
+def restarts32_pool_subprocess(ranks, iters, num_trials, model_name, timeout):
+    """The TrialWorkerPool shape of the leg in a process of its own (it must own the default process group): `python bench.py
+    --restarts32-pool RANKS`, bounded; its one JSON line is returned (an error record on failure -- never fatal for the headline)."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--restarts32-pool", str(ranks), "--restarts32-iters", str(iters),
+           "--restarts32-trials", str(num_trials), "--model", model_name]
+    try:
+        env = dict(os.environ, BREACH_HIP_POOL_START_TIMEOUT=os.environ.get("BREACH_HIP_POOL_START_TIMEOUT", str(int(timeout * 0.5))))
+        proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+        for text in reversed(proc.stdout.splitlines()):
+            if text.startswith("{"):
+                return json.loads(text)
+        return dict(error=f"no record (exit code {proc.returncode})", stderr=proc.stderr[-600:])
+    except Exception as exc:
+        return dict(error=repr(exc)[:400])
+
+
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -456,6 +593,14 @@ def parse_args():
     p.add_argument("--no-dry-collective", action="store_true",
                    help="N = 1 only: skip the one-rank RCCL run of the selection collectives (python -m breaching_amd.trials "
                         "--dry-collective, a bounded subprocess after the timed region)")
+    p.add_argument("--restarts32-iters", type=int, default=1000,
+                   help="iterations per trial of the restarts32 leg: BASELINE configs[3] (num_trials=32) through attacker.reconstruct(), "
+                        "wall time incl. scoring and selection (0 disables); N = 1: 8 groups of 4 in flight on one GPU, N > 1: sharded")
+    p.add_argument("--restarts32-trials", type=int, default=32)
+    p.add_argument("--restarts32-pool", type=int, default=0, metavar="RANKS",
+                   help="run ONLY the restarts32 leg through the single-process entry with a TrialWorkerPool of RANKS ranks (RCCL when "
+                        "every rank has a GPU, gloo oversubscribed) and print its record; bench.py --gpus N runs this in a bounded "
+                        "subprocess from rank 0 after the other ranks have left")
     p.add_argument("--trials-per-gpu", type=int, default=1,
                    help="independent restarts in flight per GPU on separate streams (BASELINE configs[3]: 32 trials on 8 GPUs = 4)")
     return p.parse_args()
@@ -471,6 +616,16 @@ def main():
     from breaching_amd.attacker import FusedTrial
     from breaching_amd.cases import build_case, initial_candidate
 
+    if args.restarts32_pool > 1:  # the pool shape of the restarts32 leg alone (a process that owns its process group)
+        for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
+            os.environ.pop(key, None)  # when started by a torch.distributed.run rank: this process is nobody's rank
+        index = int(os.environ.get("BENCH_DEVICE_INDEX", "0"))
+        torch.cuda.set_device(index)
+        record = restarts32_leg(torch.device("cuda", index), args.model, args.restarts32_iters, args.restarts32_trials,
+                                pool_world=args.restarts32_pool)
+        record["device"] = device_record(torch.device("cuda", index))
+        print(json.dumps(record), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -521,12 +676,19 @@ def main():
     # for every convolution configuration of the three autograd orders -- while the other ranks wait in front of their first
     # convolution; they then start from a COPY of rank 0's find-db: no eight concurrent searches (on one CPU, one sqlite lock) inside
     # the warm-up of the scaling run, and every rank runs the solvers rank 0 chose (equal speed, comparable results).
-    miopen_seeded = None
+    # The release is a FILE FLAG with its own limit (BENCH_STAGED_START_TIMEOUT, default 300 s), not a collective: a slow or dead rank 0
+    # must not hold seven ranks in a barrier until the collective timeout aborts the job -- on time-out they go ahead unseeded
+    # (`staged_start.released` / `.seeded_files` per rank in the line).
+    miopen_seeded, staged_released = None, None
+    staged_flag = os.path.join("/tmp", f"bench_staged_start_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}")
     if world > 1 and rank > 0:
-        dist.barrier()
+        deadline = time.time() + float(os.environ.get("BENCH_STAGED_START_TIMEOUT", "300"))
+        while not os.path.exists(staged_flag) and time.time() < deadline:
+            time.sleep(0.05)
+        staged_released = os.path.exists(staged_flag)
         from breaching_amd.workers import default_miopen_user_db, seed_miopen_user_db
 
-        if miopen_dir is not None and os.path.basename(miopen_dir).startswith("breach_hip_rank"):
+        if staged_released and miopen_dir is not None and os.path.basename(miopen_dir).startswith("breach_hip_rank"):
             miopen_seeded = seed_miopen_user_db(os.path.join(default_miopen_user_db(), "breach_hip_rank0"), miopen_dir)
 
     # ---- workload --------------------------------------------------------------------------------------------------
@@ -598,7 +760,8 @@ def main():
         step_all()
     if world > 1 and rank == 0:
         torch.cuda.synchronize(device)
-        dist.barrier()  # releases the other ranks of the staged start (above)
+        with open(staged_flag, "w") as f:  # releases the other ranks of the staged start (above)
+            f.write("warm\n")
     plan = attacker.objective._plan
     timed_with_events = plan is not None and not args.no_kernel_timing and run.graph is None
     if timed_with_events:
@@ -618,6 +781,13 @@ def main():
         everyone = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(everyone, mine)  # every rank's own wall time of the same K steps: the skew shows a straggler GPU / rank
         per_rank_ms = [round(float(v.item()) / args.steps * 1e3, 4) for v in everyone]
+        staged = [None] * world
+        dist.all_gather_object(staged, dict(rank=rank, released=staged_released, seeded_files=miopen_seeded))
+        if rank == 0:
+            try:
+                os.remove(staged_flag)
+            except OSError:
+                pass
         t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -682,10 +852,11 @@ def main():
                         # written by autograd: the achieved rate is partly a cache figure, not pure HBM
                         infinity_cache_resident=bool(fwd_bytes <= 256 * 2 ** 20))
         replay_us, replay_file = committed_replay_duration("gm_fwd_kernel<0")
-        if replay_us and args.model == "resnet18":
-            roofline["in_graph_replay"] = dict(avg_launch_us=replay_us, frac=round(fwd_bytes / replay_us / 1e3 / HBM_PEAK_GBS, 4),
-                                               source=f"rocprofv3 kernel trace of this command, committed ({replay_file}): the timed region replays a hipGraph, where "
-                                                      "event pairs cannot ride; the events above time the same kernel on eager launches")
+        if replay_us and args.model == "resnet18":  # NOT measured in this run: kept apart, under a name that says so
+            roofline["from_committed_profiles"] = dict(in_graph_replay=dict(
+                avg_launch_us=replay_us, frac=round(fwd_bytes / replay_us / 1e3 / HBM_PEAK_GBS, 4),
+                source=f"rocprofv3 kernel trace of this command, committed ({replay_file}): the timed region replays a hipGraph, where "
+                       "event pairs cannot ride; the events above time the same kernel on eager launches"))
         if "fin" in kernels:  # the whole forward stage: reduction + one-workgroup finalize
             stage_us = k["avg_us"] + kernels["fin"]["avg_us"]
             roofline.update(stage_us=round(stage_us, 2), stage_GBs=round(fwd_bytes / (stage_us * 1e-6) / 1e9, 1),
@@ -738,6 +909,14 @@ def main():
         torch.cuda.synchronize(device)
         score_ms, select_ms = (tm - ts) * 1e3, (time.perf_counter() - tm) * 1e3
 
+    # ---- BASELINE configs[3] through the product entry, one GPU: 8 groups of 4 trials in flight (after the timed region) ------
+    restarts32 = None
+    if world == 1 and args.restarts32_iters > 0 and args.model == "resnet18":
+        try:
+            restarts32 = restarts32_leg(device, args.model, args.restarts32_iters, args.restarts32_trials)
+        except Exception as exc:  # reported, never fatal for the headline value
+            restarts32 = dict(error=repr(exc)[:400])
+
     # ---- N = 1: the selection collectives through a one-rank RCCL communicator (bounded subprocess, off the timed region) ---
     rccl_dry_run = None
     if world == 1 and not args.no_dry_collective:
@@ -770,6 +949,12 @@ def main():
     if rank == 0 and world == 1 and args.cpu_baseline_iters > 0:
         cpu_baseline = cpu_baseline_leg(args.model, args.cpu_baseline_iters, args.cpu_threads)
 
+    if world > 1:
+        dist.destroy_process_group()  # ranks > 0 are done: they leave, and with them their hold on the other GPUs
+    if rank == 0 and world > 1 and args.restarts32_iters > 0 and args.model == "resnet18":
+        # BASELINE configs[3] as north_star states it: the 32 restarts over the N GPUs through the product's single-process entry
+        # (TrialWorkerPool over RCCL), in a bounded process of its own -- a failure or a time-out is a record, never a lost line
+        restarts32 = restarts32_pool_subprocess(world, args.restarts32_iters, args.restarts32_trials, args.model, timeout=900)
     if rank == 0:
         line = {
             "metric": "attack iters/sec, ResNet-18 ImageNet invertinggradients; PSNR vs ref",
@@ -804,15 +989,15 @@ def main():
             "rank_skew": None if not per_rank_ms else round(max(per_rank_ms) / min(per_rank_ms), 4),
             "select_ms": select_ms,
             "score_ms": score_ms,
+            "restarts32": restarts32,
             "rccl_dry_run": rccl_dry_run,
             "collective_backend": backend if world > 1 else None,
             "oversubscribed": bool(oversubscribed),
             "device": device_record(device),
-            "staged_start": None if world == 1 else "rank 0 warms up first; ranks > 0 start from a copy of its MIOpen find-db",
+            "staged_start": None if world == 1 else dict(how="rank 0 warms up first; ranks > 0 wait for its file flag (bounded) and start from a copy "
+                                                             "of its MIOpen find-db", ranks=staged[1:]),
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -112,57 +112,68 @@ class HipOptimizationAttacker:
     # reconstruct
     # ==============================================================================================================
     def reconstruct(self, server_payload, shared_data, server_secrets=None, initial_data=None, dryrun=False):
+        t_call = time.perf_counter()
         num_trials = self.cfg.restarts.num_trials
         preset = getattr(self, "_preset", None)  # a trial worker: starting points and labels come from rank 0
         pool = self._trial_worker_pool(num_trials) if preset is None else None
-        if pool is not None:  # host copies of the caller's inputs, taken before prepare_attack rebinds / normalises them
-            "ClassAttack" in server_secrets  # noqa: B015 -- None raises TypeError here, in the caller, as in the reference (:82)
-            job_inputs = dict(server_payload=workers.to_cpu(list(server_payload)), shared_data=workers.to_cpu(list(shared_data)),
-                              server_secrets=workers.to_cpu(server_secrets), initial_data=workers.to_cpu(initial_data), dryrun=dryrun)
-        rec_models, labels, stats = self.prepare_attack(server_payload, shared_data)
-        if preset is not None and preset["labels"] is not None:
-            labels = preset["labels"].to(self.setup["device"])
-        if pool is None and preset is None and workers.active_pool() is not None:
-            # The default process group belongs to an idle worker pool (a one-trial call on this attacker, or another
-            # attacker's pool): nobody would join a collective, so this call is a single rank.
-            shard = trials.TrialShard(num_trials)
-        else:
-            shard = trials.TrialShard.current(num_trials)
-        num_points = shared_data[0]["metadata"]["num_data_points"]
-        # Device RNG order.  The reference draws trial t's starting point right before trial t runs, and its Langevin
-        # noise draws (:169) sit between consecutive starting points.  Without noise the order of the starting-point draws
-        # is all that matters, so they are drawn up front (a sharded or concurrent run then starts every trial exactly
-        # where the sequential run does).  With noise on a single rank the reference's interleaving is kept: trials run
-        # one at a time and each draws its start when its turn comes.  Only noise + several ranks deviates (documented).
-        noisy = float(self.cfg.optim.langevin_noise or 0.0) > 0
-        lazy_draws = noisy and shard.world == 1
-        if preset is not None:
-            inits = {t: self._adopt_initial_state(state) for t, state in preset["inits"].items()}
-        else:
-            inits = {} if lazy_draws else {t: self._draw_initial_state(num_points, labels) for t in range(num_trials)}
-        if pool is not None:  # rank r gets the starting points of its trials, drawn here in the reference's order
-            pool.submit([dict(job_inputs, labels=workers.to_cpu(labels),
-                              inits={t: workers.to_cpu(tuple(inits[t])) for t in range(r, num_trials, pool.world)})
-                         for r in range(1, pool.world)])
-
-        local_scores, local_solutions = {}, {}
-        mine = list(shard.local_trials())
-        width = trials_in_flight(self.cfg) if (self._fused_loop_supported() and not noisy) else 1
         self._trial_execution = {}
+        timing = dict(prepare_s=0.0, trials_s=0.0, score_s=0.0, select_s=0.0)
         try:
+            if pool is not None:
+                "ClassAttack" in server_secrets  # noqa: B015 -- None raises TypeError here, in the caller, as in the reference (:82)
+                # The caller's inputs go to the workers BEFORE prepare_attack rebinds / normalises them (base_attack.py:214-220,
+                # :298-303 work in place), as one broadcast per dtype over the pool's communicator; nothing tensor-valued is
+                # copied to the host or pickled (round 6; servers.py:138-147 / users.py:176-183 define what must arrive).
+                pool.begin_job()
+                pool.ship("inputs", dict(server_payload=list(server_payload), shared_data=list(shared_data),
+                                         server_secrets=server_secrets, initial_data=initial_data), self.setup["device"])
+            rec_models, labels, stats = self.prepare_attack(server_payload, shared_data)
+            if preset is not None and preset["labels"] is not None:
+                labels = preset["labels"].to(self.setup["device"])
+            if pool is None and preset is None and workers.active_pool() is not None:
+                # The default process group belongs to an idle worker pool (a one-trial call on this attacker, or another
+                # attacker's pool): nobody would join a collective, so this call is a single rank.
+                shard = trials.TrialShard(num_trials)
+            else:
+                shard = trials.TrialShard.current(num_trials)
+            num_points = shared_data[0]["metadata"]["num_data_points"]
+            # Device RNG order.  The reference draws trial t's starting point right before trial t runs, and its Langevin
+            # noise draws (:169) sit between consecutive starting points.  Without noise the order of the starting-point draws
+            # is all that matters, so they are drawn up front (a sharded or concurrent run then starts every trial exactly
+            # where the sequential run does).  With noise on a single rank the reference's interleaving is kept: trials run
+            # one at a time and each draws its start when its turn comes.  Only noise + several ranks deviates (documented).
+            noisy = float(self.cfg.optim.langevin_noise or 0.0) > 0
+            lazy_draws = noisy and shard.world == 1
+            if preset is not None:
+                inits = {t: self._adopt_initial_state(state) for t, state in preset["inits"].items()}
+            else:
+                inits = {} if lazy_draws else {t: self._draw_initial_state(num_points, labels) for t in range(num_trials)}
+            if pool is not None:  # the starting points of the workers' trials, drawn here in the reference's order
+                pool.ship("starts", dict(labels=labels, inits={t: tuple(inits[t]) for t in range(num_trials) if t % pool.world != 0}),
+                          self.setup["device"])
+                pool.submit([dict(dryrun=dryrun)] * (pool.world - 1))
+            timing["prepare_s"] = time.perf_counter() - t_call
+
+            local_scores, local_solutions = {}, {}
+            mine = list(shard.local_trials())
+            width = trials_in_flight(self.cfg) if (self._fused_loop_supported() and not noisy) else 1
             try:
                 for start in range(0, len(mine), max(width, 1)):
                     group = mine[start : start + max(width, 1)]
+                    t_group = time.perf_counter()
                     if len(group) == 1:
                         solutions = {group[0]: self._run_trial(rec_models, shared_data, labels, stats, group[0], initial_data,
                                                                dryrun, init_state=inits.get(group[0]))}
                     else:
                         solutions = self._run_trial_group(rec_models, shared_data, labels, stats, group, initial_data, dryrun,
                                                           {t: inits[t] for t in group})
+                    t_score = time.perf_counter()
+                    timing["trials_s"] += t_score - t_group
                     for trial, solution in solutions.items():
                         local_solutions[trial] = solution
                         local_scores[trial] = self._score_trial(self._solution_data(solution),
                                                                 self._score_labels(solution, labels), rec_models, shared_data)
+                    timing["score_s"] += time.perf_counter() - t_score
             except KeyboardInterrupt:
                 print("Trial procedure manually interruped.")
             if pool is not None:
@@ -176,12 +187,13 @@ class HipOptimizationAttacker:
             stats["execution_trials"] = dict(self._trial_execution)  # merged over the ranks with the loss histories
             t_select = time.perf_counter()
             optimal = self._select_optimal_reconstruction(local_solutions, local_scores, stats, shard)
+            timing["select_s"] = time.perf_counter() - t_select
             if pool is not None:
-                pool.timing["select_s"] = round(time.perf_counter() - t_select, 4)
+                pool.timing["select_s"] = round(timing["select_s"], 4)
                 pool.finish()
         except BaseException:
-            # A failure on any rank between `submit` and the last `ok` -- a worker's error report, or this rank's own trials
-            # raising -- must not leave healthy workers waiting for a `go` that never comes (the next call would read their
+            # A failure on any rank between the first `ship` and the last `ok` -- a worker's error report, or this rank's own
+            # trials raising -- must not leave healthy workers waiting for a `go` that never comes (the next call would read their
             # stale messages and enter the collective alone): cancel the job everywhere; a pool that cannot be drained is
             # closed, and the next call starts a new one.
             if pool is not None:
@@ -190,11 +202,14 @@ class HipOptimizationAttacker:
                     self._pool = None
             raise
         # How this call was executed, on the channel callers already read (base_attack.py:45): per-trial launch mode of
-        # this rank's trials, the pool that shared the trials (backend, world, devices) or why there was none.
+        # this rank's trials, the pool that shared the trials (backend, world, devices) or why there was none, and where this
+        # rank's wall time went (`timing`: preparation incl. shipping, the trial loops, rescoring :191-204, selection :206-218).
+        timing["total_s"] = time.perf_counter() - t_call
         stats["execution"] = dict(trials=stats.pop("execution_trials"), pool=pool.describe() if pool is not None else None,
                                   fused_epilogue_fallback=getattr(self, "fused_epilogue_fallback", None),
                                   pool_fallback=getattr(self, "_pool_fallback", None), world=shard.world,
-                                  trial_streams=trial_streams.calibration_report(self.setup["device"]))
+                                  trial_streams=trial_streams.calibration_report(self.setup["device"]),
+                                  timing={k: round(v, 4) for k, v in timing.items()})
         reconstructed_data = self._package(optimal, labels)
         if server_payload[0]["metadata"].modality == "text":
             raw = reconstructed_data["data"]

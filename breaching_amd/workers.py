@@ -11,8 +11,17 @@ of ``trials.TrialShard.select``.  The rendezvous (RCCL unique id included) goes 
 reference: the sequential trial loop of breaching/attacks/optimization_based_attack.py:70-78 -- the reference has no
 multi-device code, this is an MI355X-native addition behind the unchanged ``reconstruct`` signature.
 
-Protocol (one duplex pipe per worker):  parent -> worker ``("job", dict)`` | ``("go",)`` | ``("abort",)`` | ``("stop",)``;
-worker -> parent ``("booted",)`` as the first statement of the child (its arguments unpickled, i.e. the victim model class is
+Job inputs do NOT travel over the pipes (round 6): the model parameters, the observed gradients, buffers, labels and starting points
+of a call are broadcast from rank 0 over the communicator the pool already owns (`TrialWorkerPool.ship`: one flat buffer per
+dtype, device to device over xGMI with "nccl"); the pipe carries the skeleton of the containers -- shapes, dtypes, metadata.
+reference: what has to arrive is what the server / user hand to `reconstruct`, breaching/cases/servers.py:138-147 and
+breaching/cases/users.py:176-183.
+
+Protocol (one duplex pipe per worker):  parent -> worker ``("ship", key, skeleton, specs)`` | ``("ship_go",)`` | ``("job", dict)`` |
+``("go",)`` | ``("abort",)`` | ``("stop",)``;
+worker -> parent ``("ship_ready",)`` once the receive buffers of a shipment are allocated (the parent answers ``ship_go`` when
+every worker said so and all ranks enter the broadcast together; a failure on any rank turns into ``abort`` instead),
+``("booted",)`` as the first statement of the child (its arguments unpickled, i.e. the victim model class is
 importable there), ``("ready",)`` once its process group is up, ``("trials_done",)`` when its trials are finished -- it then
 waits for ``("go",)`` from the parent before entering the selection collective -- ``("ok",)`` when the job is finished,
 ``("error", traceback)`` on failure, ``("aborted",)`` in answer to ``abort``.  The parent sends ``go`` only after every
@@ -68,32 +77,97 @@ def rendezvous(conn):
         raise RuntimeError(f"trial worker protocol error: expected 'go', got {message[0]!r}")
 
 
-def to_device(obj, device):
-    """Nested lists / tuples / dicts with every tensor moved to `device` (containers are rebuilt, other leaves shared)."""
-    if torch.is_tensor(obj):
-        return obj.to(device)
-    if isinstance(obj, dict):
-        return type(obj)((k, to_device(v, device)) for k, v in obj.items())
-    if isinstance(obj, (list, tuple)):
-        return type(obj)(to_device(v, device) for v in obj)
-    return obj
-
-
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def to_cpu(obj):
-    """Deep copy of nested lists / tuples / dicts with every tensor moved to host memory (what travels over the pipe)."""
+# ---- shipping job inputs over the process group instead of the pipes ---------------------------------------------------
+SHIP_ALIGN_BYTES = 512  # every tensor of a shipment starts on a 512-byte boundary of its flat buffer (the caching allocator's grain)
+
+
+class _Slot:
+    """Placeholder of tensor number `index` in the skeleton of a shipment."""
+
+    __slots__ = ("index",)
+
+    def __init__(self, index):
+        self.index = index
+
+    def __reduce__(self):
+        return (_Slot, (self.index,))
+
+
+def split_tensors(obj, tensors=None, seen=None):
+    """(skeleton, tensors): nested lists / tuples / dicts rebuilt with every tensor replaced by a `_Slot`; a tensor object that
+    occurs twice (public buffers named by the payload and by the user update) is shipped once."""
+    if tensors is None:
+        tensors, seen = [], {}
     if torch.is_tensor(obj):
-        return obj.detach().to("cpu")
+        index = seen.get(id(obj))
+        if index is None:
+            index = seen[id(obj)] = len(tensors)
+            tensors.append(obj)
+        return _Slot(index), tensors
     if isinstance(obj, dict):
-        return type(obj)((k, to_cpu(v)) for k, v in obj.items())
+        return type(obj)((k, split_tensors(v, tensors, seen)[0]) for k, v in obj.items()), tensors
     if isinstance(obj, (list, tuple)):
-        return type(obj)(to_cpu(v) for v in obj)
-    return obj
+        return type(obj)(split_tensors(v, tensors, seen)[0] for v in obj), tensors
+    return obj, tensors
+
+
+def join_tensors(skeleton, tensors):
+    """Inverse of `split_tensors`."""
+    if isinstance(skeleton, _Slot):
+        return tensors[skeleton.index]
+    if isinstance(skeleton, dict):
+        return type(skeleton)((k, join_tensors(v, tensors)) for k, v in skeleton.items())
+    if isinstance(skeleton, (list, tuple)):
+        return type(skeleton)(join_tensors(v, tensors) for v in skeleton)
+    return skeleton
+
+
+def shipment_layout(specs):
+    """Flat-buffer layout of a shipment: {dtype name: (total elements, [(tensor index, element offset, numel), ...])}, one
+    buffer per dtype in order of first appearance, every tensor on a SHIP_ALIGN_BYTES boundary."""
+    layout = {}
+    for index, (shape, dtype_name) in enumerate(specs):
+        grain = max(SHIP_ALIGN_BYTES // torch.empty(0, dtype=getattr(torch, dtype_name)).element_size(), 1)
+        total, members = layout.get(dtype_name, (0, []))
+        numel = int(torch.Size(shape).numel())
+        members.append((index, total, numel))
+        layout[dtype_name] = ((total + numel + grain - 1) // grain * grain, members)
+    return layout
+
+
+def _collective_device(backend, device):
+    return torch.device("cpu") if backend == "gloo" or device is None else torch.device(device)
+
+
+def receive_shipment(conn, skeleton, specs, backend, device):
+    """Worker side of `TrialWorkerPool.ship`: allocate the flat receive buffers, report `ship_ready`, wait for `ship_go` (or
+    `abort`), join the broadcasts, rebuild the containers around views of the buffers (moved to `device` when the collective
+    ran on the host: gloo)."""
+    import torch.distributed as dist
+
+    cdev = _collective_device(backend, device)
+    layout = shipment_layout(specs)
+    flats = {name: torch.empty(total, dtype=getattr(torch, name), device=cdev) for name, (total, _) in layout.items()}
+    conn.send(("ship_ready",))
+    message = conn.recv()
+    if message[0] == "abort":
+        raise JobAborted()
+    if message[0] != "ship_go":
+        raise RuntimeError(f"trial worker protocol error: expected 'ship_go', got {message[0]!r}")
+    tensors = [None] * len(specs)
+    for name, (total, members) in layout.items():
+        if total > 0:
+            dist.broadcast(flats[name], src=0)
+        for index, offset, numel in members:
+            view = flats[name][offset : offset + numel].view(specs[index][0])
+            tensors[index] = view if device is None or cdev == torch.device(device) else view.to(device)
+    return join_tensors(skeleton, tensors)
 
 
 def default_miopen_user_db():
@@ -183,17 +257,32 @@ def _worker_main(rank, world, port, backend, device_index, conn, runner_factory,
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout), **kwargs)
         runner = runner_factory(rank, world, device_index, conn, *factory_args)
         conn.send(("ready",))
+        device = None if device_index is None else torch.device("cuda", device_index)
+        shipped = {}  # what `TrialWorkerPool.ship` delivered for the job that follows
         while True:
             message = conn.recv()
             if message[0] == "stop":
                 break
             if message[0] == "abort":  # the job this refers to is already over here (finished or failed): acknowledge
+                shipped = {}
                 conn.send(("aborted",))
+                continue
+            if message[0] == "ship":
+                try:
+                    shipped[message[1]] = receive_shipment(conn, message[2], message[3], backend, device)
+                except JobAborted:
+                    shipped = {}
+                    conn.send(("aborted",))
+                except Exception:
+                    shipped = {}
+                    conn.send(("error", traceback.format_exc()))
                 continue
             if message[0] != "job":  # e.g. a `go` that crossed an error report
                 continue
             try:
-                runner(message[1])
+                job, shipped = dict(message[1], **shipped), {}
+                runner(job)
+                del job
                 conn.send(("ok",))
             except JobAborted:
                 conn.send(("aborted",))
@@ -282,7 +371,8 @@ class TrialWorkerPool:
     def describe(self):
         """What a caller gets to see in `stats["execution"]["pool"]`: the group, and where the wall time outside the trials
         went -- `pool_start_s` (spawn + imports + communicator + worker attackers; paid by the first call only),
-        `job_ship_s` (host copies of the inputs pickled down the pipes), `trials_wait_s` (rank 0 waiting for the slowest
+        `job_ship_s` (inputs and starting points: skeletons down the pipes, `job_pipe_bytes` each, tensor contents in
+        broadcasts over the group, `job_ship_bytes`), `trials_wait_s` (rank 0 waiting for the slowest
         worker after its own trials), `select_s` (all-reduce + broadcast + history gather)."""
         return dict(backend=self.backend, world=self.world, devices=list(self.devices), **self.timing)
 
@@ -295,7 +385,47 @@ class TrialWorkerPool:
         self.busy = True
         for (proc, conn), job in zip(self.workers, jobs):
             conn.send(("job", job))
-        self.timing["job_ship_s"] = round(time.perf_counter() - t0, 4)
+        self.timing["job_ship_s"] = round(self.timing.get("job_ship_s", 0.0) + time.perf_counter() - t0, 4)
+
+    def ship(self, key, tree, device=None):
+        """Deliver `tree` (nested lists / tuples / dicts of tensors and small picklable leaves) to every worker as
+        ``job[key]`` of the job submitted next.  The pipes carry the skeleton (shapes, dtypes, metadata); the tensor contents
+        travel in ONE broadcast per dtype from rank 0 over the pool's process group -- device to device (RCCL over xGMI) with
+        "nccl", host buffers with "gloo" (ranks sharing a GPU: the functional path of a 1-GPU box).  Every rank enters the
+        broadcast only after ALL workers allocated their receive buffers (`ship_ready` -> `ship_go`); a worker that died or
+        failed raises here, before anyone waits in a collective.  Adds to `timing["job_ship_s"]`; `job_ship_bytes` /
+        `job_pipe_bytes` count what went over the group and over each pipe."""
+        import pickle
+        import time
+
+        import torch.distributed as dist
+
+        t0 = time.perf_counter()
+        self.busy = True
+        skeleton, tensors = split_tensors(tree)
+        specs = [(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in tensors]
+        cdev = _collective_device(self.backend, device)
+        message = ("ship", key, skeleton, specs)
+        self.timing["job_pipe_bytes"] = self.timing.get("job_pipe_bytes", 0) + len(pickle.dumps(message))
+        for proc, conn in self.workers:
+            conn.send(message)
+        self.expect("ship_ready")
+        self.broadcast(("ship_go",))
+        for name, (total, members) in shipment_layout(specs).items():
+            if total == 0:
+                continue
+            flat = torch.empty(total, dtype=getattr(torch, name), device=cdev)
+            for index, offset, numel in members:
+                flat[offset : offset + numel].copy_(tensors[index].detach().reshape(-1))
+            dist.broadcast(flat, src=0)
+            self.timing["job_ship_bytes"] = self.timing.get("job_ship_bytes", 0) + flat.numel() * flat.element_size()
+        if cdev.type == "cuda":
+            torch.cuda.synchronize(cdev)
+        self.timing["job_ship_s"] = round(self.timing.get("job_ship_s", 0.0) + time.perf_counter() - t0, 4)
+
+    def begin_job(self):
+        """Reset the per-job timing record (everything but `pool_start_s`)."""
+        self.timing = {k: v for k, v in self.timing.items() if k == "pool_start_s"}
 
     def finish(self):
         """Every worker reported `ok`: the job is over."""
@@ -406,15 +536,16 @@ def attacker_runner_factory(rank, world, device_index, conn, attack_class_name, 
     att._is_trial_worker = True
 
     def run(job):
-        att._preset = dict(inits=job["inits"], labels=job["labels"])
+        # `inputs` and `starts` arrived through `TrialWorkerPool.ship`: tensors already on this rank's device (the reference
+        # only casts gradients and buffers, base_attack.py:214-220, because its caller's tensors live on the attack device;
+        # e.g. the FedAvg labels in metadata.local_hyperparams are used as they are), containers private to this job.
+        inputs, starts = job["inputs"], job["starts"]
+        mine = {t: state for t, state in starts["inits"].items() if t % world == rank}
+        att._preset = dict(inits=mine, labels=starts["labels"])
         att._before_select = lambda: rendezvous(conn)
         try:
-            # Everything tensor-valued moves to this rank's device up front -- the reference only casts gradients and
-            # buffers (base_attack.py:214-220) because its caller's tensors already live on the attack device; here
-            # they arrive as host copies, and e.g. the FedAvg labels in metadata.local_hyperparams are used as they are.
-            shared_data = to_device(job["shared_data"], device)
-            server_secrets = to_device(job["server_secrets"], device)
-            att.reconstruct(job["server_payload"], shared_data, server_secrets, job["initial_data"], job["dryrun"])
+            att.reconstruct(inputs["server_payload"], inputs["shared_data"], inputs["server_secrets"], inputs["initial_data"],
+                            job["dryrun"])
         finally:
             att._preset, att._before_select = None, None
 

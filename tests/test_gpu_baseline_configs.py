@@ -584,6 +584,10 @@ def test_reconstruct_shards_trials_over_worker_processes_and_matches_one_rank():
                 assert {k: pool[k] for k in ("backend", "world", "devices")} == dict(backend="gloo", world=2, devices=[0, 0])
                 # where the wall time outside the trials went (what an 8-GPU run will be read by): all present, all sane
                 assert pool["pool_start_s"] > 0 and pool["job_ship_s"] >= 0 and pool["trials_wait_s"] >= 0 and pool["select_s"] > 0
+                # round 6: the inputs travel by broadcast over the group -- every parameter and gradient element once -- and the pipes
+                # carry the skeleton only
+                n_model = sum(p.numel() for p in case.model.parameters())
+                assert pool["job_ship_bytes"] >= 2 * n_model * 4 and pool["job_pipe_bytes"] < 64 * 1024
                 assert stats["execution"]["pool_fallback"] is None and stats["execution"]["world"] == 2
                 # the launch mode of every trial, the worker's included, reaches the caller
                 assert stats["execution"]["trials"] == {t: "hipGraph replay" for t in range(4)}

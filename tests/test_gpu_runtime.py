@@ -176,7 +176,8 @@ def test_bench_line_contract():
     a measured read `ceiling`), `parity` (teacher-forced evaluation against the reference fixture, ok), `gpu_torch_baseline` (the port
     on the same GPU, slower than the HIP path), `cpu_baseline`."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-baseline-iters", "2",
-           "--gpu-torch-baseline-iters", "4", "--roofline-steps", "6", "--no-live-pmc", "--no-hbm-resident", "--no-dry-collective"]
+           "--gpu-torch-baseline-iters", "4", "--roofline-steps", "6", "--no-live-pmc", "--no-hbm-resident", "--no-dry-collective",
+           "--restarts32-iters", "12", "--restarts32-trials", "8"]
     proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")]
@@ -195,9 +196,49 @@ def test_bench_line_contract():
     assert 5.0 < roof["ceiling"]["us"] < 40.0 and 0.5 < roof["frac_of_ceiling"] <= 1.1
     parity = line["parity"]
     assert parity["ok"] is True and parity["iterate"] > 23_000 and parity["loss_rel_err"] <= parity["loss_tolerance"]
+    # the gate is tied to the same-arithmetic control of the same run (PyTorch-ROCm ops on this GPU), and the HIP path sits with it
+    control = parity["control"]
+    assert parity["loss_tolerance"] == pytest.approx(max(1e-4, 3.0 * control["loss_rel_err"])) and control["sign_agreement"] > 0.99
+    assert parity["loss_hip_vs_control_rel"] <= max(1e-4, 3.0 * control["loss_rel_err"])
     assert parity["sign_agreement"] > 0.99 > parity["reference_twin_agreement"] > 0.9
     assert 0 < line["gpu_torch_baseline"]["value"] < line["value"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] in ("reference", "port")
+    _check_restarts_leg(line["restarts32"], trials=8, iters=12, ranks=1)
+    assert line["restarts32"]["pool"] is None and line["restarts32"]["entry"] == "one process, one GPU"
+
+
+def _check_restarts_leg(leg, trials, iters, ranks):
+    """Contract of bench.py's `restarts32` record (BASELINE configs[3] through `attacker.reconstruct`): the whole call is timed --
+    shipping, preparation, the trial loops, rescoring every trial, selection -- and accounted for."""
+    assert "error" not in leg, leg
+    assert leg["num_trials"] == trials and leg["iterations_per_trial"] == iters and leg["ranks"] == ranks
+    assert leg["trials_per_rank"] == -(-trials // ranks) and leg["trials_in_flight_per_rank"] == min(4, -(-trials // ranks))
+    assert leg["histories_complete"] is True and leg["launch_modes"] == ["hipGraph replay"]
+    assert leg["trial_iterations_per_s"] == pytest.approx(trials * iters / leg["wall_s"], rel=1e-2) and leg["wall_s"] > 0
+    timing = leg["timing_rank0"]
+    parts = timing["prepare_s"] + timing["trials_s"] + timing["score_s"] + timing["select_s"]
+    assert timing["trials_s"] > 0 and timing["score_s"] > 0 and parts <= timing["total_s"] * 1.001 <= leg["wall_s"] * 1.01
+    assert parts >= 0.9 * timing["total_s"] or ranks > 1  # rank 0 of a pool also waits for the slowest worker (pool.trials_wait_s)
+    assert np.isfinite(leg["opt_value"]) and 0 < leg["opt_value"] < 2 and 3.0 < leg["psnr_db_selected"] < 60.0
+    assert leg["warmup_call_s"] > 0
+
+
+@pytest.mark.trial_pool
+def test_bench_restarts_leg_through_the_worker_pool():
+    """`bench.py --restarts32-pool 2`: the leg's multi-GPU shape -- the single-process entry with a TrialWorkerPool -- as the N > 1
+    bench runs it from rank 0 in a bounded subprocess; here two ranks share cuda:0 (gloo, `oversubscribed`).  The inputs of the
+    ResNet-18 call (2 x 46.8 MB of parameters and gradients) reach the worker by broadcast over the group: the pipe carries
+    kilobytes (VERDICT round 5, next #2)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--restarts32-pool", "2", "--restarts32-iters", "12", "--restarts32-trials", "8"]
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    leg = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    print(" ", {k: leg[k] for k in ("wall_s", "trial_iterations_per_s", "warmup_call_s", "pool")})
+    _check_restarts_leg(leg, trials=8, iters=12, ranks=2)
+    pool = leg["pool"]
+    assert pool["backend"] == ("gloo" if leg["oversubscribed"] else "nccl") and pool["world"] == 2
+    assert pool["job_ship_bytes"] >= 2 * 11_689_512 * 4 and pool["job_pipe_bytes"] < 256 * 1024
+    assert pool["job_ship_s"] > 0 and pool["trials_wait_s"] >= 0 and pool["select_s"] > 0 and leg["warmup_pool"]["pool_start_s"] > 0
 
 
 def test_graph_capture_with_a_live_rccl_process_group():

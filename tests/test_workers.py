@@ -209,3 +209,99 @@ def test_eight_ranks_share_32_restarts_like_an_eight_gpu_node():
     finally:
         pool.close(force=True)
     assert workers.active_pool() is None
+
+
+def _shipping_runner_factory(rank, world, device_index, conn):
+    """Stand-in for `attacker_runner_factory`: checks what `TrialWorkerPool.ship` delivered and reports a checksum back through the
+    selection collective (score = what this rank saw)."""
+    from breaching_amd import trials
+    from breaching_amd.workers import rendezvous
+
+    def run(job):
+        inputs, starts = job["inputs"], job["starts"]
+        grads = inputs["shared_data"][0]["gradients"]
+        assert inputs["shared_data"][0]["metadata"]["name"] == "meta" and inputs["server_secrets"] == {} and inputs["initial_data"] is None
+        assert [tuple(g.shape) for g in grads] == [(3, 5), (7,), (0,), (2, 2, 2)] and grads[3].dtype == torch.float64
+        assert inputs["server_payload"][0]["buffers"][0] is inputs["shared_data"][0]["buffers"][0]  # one object shipped once
+        assert inputs["server_payload"][0]["buffers"][0].dtype == torch.int64
+        assert all(g.data_ptr() % 64 == 0 for g in grads if g.numel() > 0)  # 512-byte grain inside the flat buffer (the host allocator aligns to 64)
+        mine = {t: s for t, s in starts["inits"].items() if t % world == rank}
+        assert sorted(mine) == list(range(rank, job["num_trials"], world)) and 0 not in starts["inits"]
+        checksum = float(sum(g.double().sum() for g in grads) + inputs["server_payload"][0]["buffers"][0].sum()
+                         + sum(float(s[0].sum()) for s in mine.values()) + float(starts["labels"].sum()))
+        shard = trials.TrialShard.current(job["num_trials"])
+        rendezvous(conn)
+        shard.select({t: s[0] for t, s in mine.items()}, {t: checksum + t for t in mine}, {}, torch.device("cpu"))
+
+    return run
+
+
+def test_job_inputs_travel_over_the_process_group_not_the_pipes():
+    """Round 6: `reconstruct` hands its inputs to the workers through `pool.ship` -- the pipes carry shapes, dtypes and metadata, the
+    tensor contents one broadcast per dtype over the pool's own group (gloo here, RCCL when every rank has a GPU).  Mixed dtypes,
+    empty and shared tensors, two shipments per job (inputs before prepare_attack, starting points after), pipe bytes independent
+    of the tensor sizes, and a failure between the two shipments aborts cleanly."""
+    from breaching_amd import trials, workers
+    from breaching_amd.workers import TrialWorkerPool
+
+    num_trials = 6
+    pool = TrialWorkerPool([None, None, None], _shipping_runner_factory, ())
+    try:
+        pipe_bytes = []
+        for scale in (1, 64):
+            gen = torch.Generator().manual_seed(scale)
+            grads = [torch.randn(3, 5, generator=gen), torch.randn(7, generator=gen), torch.zeros(0), torch.randn(2, 2, 2, generator=gen, dtype=torch.float64)]
+            big = torch.randn(1000 * scale, generator=gen)  # rides along in the metadata-free part: only its size changes
+            buffers = [torch.arange(4)]
+            payload = [dict(parameters=[big], buffers=buffers, metadata="cfg")]
+            shared = [dict(gradients=grads, buffers=buffers, metadata=dict(name="meta", labels=None))]
+            inits = {t: (torch.full((1, 3, 4, 4), float(t)).requires_grad_(True),) for t in range(num_trials)}
+            labels = torch.tensor([3, 1])
+            pool.begin_job()
+            pool.ship("inputs", dict(server_payload=payload, shared_data=shared, server_secrets={}, initial_data=None))
+            pool.ship("starts", dict(labels=labels, inits={t: inits[t] for t in range(num_trials) if t % 3 != 0}))
+            pool.submit([dict(num_trials=num_trials)] * 2)
+            shard = trials.TrialShard.current(num_trials)
+            pool.expect("trials_done")
+            pool.broadcast(("go",))
+            base = float(sum(g.double().sum() for g in grads) + 6 + 4)
+            own = base + sum(float(inits[t][0].sum()) for t in (0, 3))
+            value, solution = shard.select({t: inits[t][0].detach() for t in (0, 3)}, {0: own, 3: own + 3}, {}, torch.device("cpu"))
+            pool.finish()
+            per_rank = {r: base + sum(float(inits[t][0].sum()) for t in range(r, num_trials, 3)) + r for r in range(3)}  # trial r is rank r's best
+            winner = min(per_rank, key=per_rank.get)
+            assert value == pytest.approx(per_rank[winner], rel=1e-6) and float(solution.flatten()[0]) == float(winner)
+            timing = pool.describe()
+            assert timing["job_ship_s"] > 0 and timing["job_ship_bytes"] >= big.numel() * 4
+            pipe_bytes.append(timing["job_pipe_bytes"])
+        assert pipe_bytes[1] - pipe_bytes[0] < 64  # 64x the tensor bytes, the same skeleton on the pipe (digits of the shapes aside)
+        # a failure between the shipments (rank 0's prepare_attack raising): the workers hold a shipment and wait for more
+        pool.begin_job()
+        pool.ship("inputs", dict(server_payload=payload, shared_data=shared, server_secrets={}, initial_data=None))
+        assert pool.busy
+        pool.abort()
+        assert not pool.closed and not pool.busy
+        pool.begin_job()
+        pool.ship("inputs", dict(server_payload=payload, shared_data=shared, server_secrets={}, initial_data=None))
+        pool.ship("starts", dict(labels=labels, inits={t: inits[t] for t in range(num_trials) if t % 3 != 0}))
+        pool.submit([dict(num_trials=num_trials)] * 2)
+        pool.expect("trials_done")
+        pool.broadcast(("go",))
+        shard.select({t: inits[t][0].detach() for t in (0, 3)}, {0: 1e9, 3: 1e9}, {}, torch.device("cpu"))
+        pool.finish()
+    finally:
+        pool.close(force=True)
+    assert workers.active_pool() is None
+
+
+def test_split_and_join_tensors_round_trip():
+    from breaching_amd.workers import join_tensors, shipment_layout, split_tensors
+
+    a, b = torch.arange(6.0).view(2, 3), torch.arange(3)
+    tree = dict(x=[a, (b, a)], y=None, z={"k": 4})
+    skeleton, tensors = split_tensors(tree)
+    assert len(tensors) == 2 and tensors[0] is a and tensors[1] is b
+    back = join_tensors(skeleton, tensors)
+    assert back["x"][0] is a and back["x"][1][1] is a and back["x"][1][0] is b and back["y"] is None and back["z"] == {"k": 4}
+    layout = shipment_layout([((2, 3), "float32"), ((3,), "int64"), ((5,), "float32")])
+    assert layout["float32"] == (256, [(0, 0, 6), (2, 128, 5)]) and layout["int64"] == (64, [(1, 0, 3)])
