@@ -275,14 +275,28 @@ def read_ceiling_leg(device, n_elements, kernel_us, reps=30):
 def parity_leg(device, model_name):
     """The timed configuration against the unmodified reference, in one evaluation: at the reference's own iterate x_k of its
     24 000-iteration CPU run (the latest stored one, k = 23 991; tests/golden/attack_resnet18_24k.npz, written by
-    oracle/make_golden.py golden_resnet18_24k) the HIP path's objective (kernel A forward behind the victim's double backward +
-    kernel C) against the reference's history[k], and sign(d total / dx) -- what hard-sign Adam consumes -- against the
-    reference's sign map, next to the reference's OWN agreement with itself when x_k moves by <= 16 ulp."""
+    oracle/make_golden.py golden_resnet18_24k) the objective and sign(d total / dx) -- what hard-sign Adam consumes -- against the
+    reference's history[k] and sign map, next to the reference's OWN agreement with itself when x_k moves by <= 16 ulp.
+
+    Three evaluations on this GPU, so that a deviation from the CPU reference has an owner:
+      * `control`      PyTorch-ROCm ops only -- oracle/restate.py's statements (the checker, pinned to the reference by
+                       tests/test_oracle_pinning.py), torch's own BatchNorm; no kernel of libbreach_hip.so.  Its deviation from the
+                       CPU reference is MIOpen-vs-oneDNN in the victim's convolutions at a kink-dense late iterate.
+      * `kernels_A_C`  the HIP objective and prior (kernel A behind the double backward, kernel C) on the STOCK BatchNorm modules:
+                       the same victim arithmetic as the control, so |kernels_A_C - control| is what the attack-side kernels add.
+                       Held to north_star's 1e-4 outright.
+      * the timed path kernels A, C AND kernel E (eval BatchNorm as y = x * s_c + t_c, one rounding away from torch's
+                       (x - mean) * inv_std * w + b): last-ulp differences in the activations move ReLU kinks, which is what the
+                       fixture's recorded `kink_sensitivity` measures on the reference itself (its loss moves that much when x_k
+                       moves <= 16 ulp).  Held to max(1e-4, 3 x the control's own deviation, 3 x that sensitivity)."""
+    import copy
+
     import numpy as np
     import torch
 
     import breaching_amd
     from breaching_amd.cases import build_case, parameter_checksum
+    from oracle import restate
 
     path = os.path.join(ROOT, "tests", "golden", "attack_resnet18_24k.npz")
     if model_name != "resnet18" or not os.path.exists(path):
@@ -291,59 +305,67 @@ def parity_leg(device, model_name):
     case = build_case("resnet18", "ImageNet", 1, device=device)  # observed gradient computed on the CPU: the target the reference attacked
     if abs(parameter_checksum(case.model) / float(gold["model_checksum"]) - 1) > 1e-10:
         return dict(error="model of this run differs from the fixture's")
-    cfg = breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={int(gold['iterations'])}"])
-    attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, dict(device=device, dtype=torch.float))
-    shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
-    rec_models, labels, _ = attacker.prepare_attack(case.server_payload, shared)
-    for reg in attacker.regularizers:
-        reg.initialize(rec_models, shared, labels)
-    attacker.objective.initialize(attacker.loss_fn, cfg.impl, None)
-    attacker.objective.prepare(rec_models, shared)
     i = int(np.argmax(gold["forced_k"]))
     k = int(gold["forced_k"][i])
-    xk = torch.as_tensor(gold["forced_x"][i]).to(device).clone().requires_grad_(True)
-    total, _ = attacker._autograd_objective([xk], labels, rec_models, shared, attacker.regularizers)
-    (g,) = torch.autograd.grad(total, [xk])
-    g = g.detach().cpu()
     sign_ref = torch.as_tensor(gold["forced_sign"][i].astype(np.float32))
     weight = torch.as_tensor((gold["forced_grad_bf16"][i].astype(np.uint32) << 16).view(np.float32)).abs().double()
-    same = (torch.sign(g) == sign_ref).double()
     want = float(gold["history"][k])
-    ref_psnr = np.concatenate([[gold["psnr"]], gold["twin_psnr"]])
-    # The same-arithmetic control: the SAME evaluation at the same iterate on the same GPU with PyTorch-ROCm ops throughout --
-    # oracle/restate.py's statements (the checker, pinned to the reference by tests/test_oracle_pinning.py), torch's own BatchNorm,
-    # no kernel of libbreach_hip.so.  Its deviation from the CPU reference is MIOpen-vs-oneDNN in the victim's convolutions at a
-    # kink-dense late iterate; what the HIP path adds on top is |hip - control|.  The gate is 3x the control's own deviation
-    # (never below north_star's 1e-4), not a multiple of the recorded kink sensitivity.
-    import copy
 
-    from oracle import restate
+    def against_reference(total, grad):
+        same = (torch.sign(grad.detach().cpu()) == sign_ref).double()
+        return dict(loss=float(total.detach()), loss_rel_err=abs(float(total.detach()) - want) / want, sign_agreement=float(same.mean()),
+                    weighted_sign_agreement=float((same * weight).sum() / weight.sum()))
 
+    def hip_evaluation(extra):
+        cfg = breaching_amd.get_attack_config("invertinggradients", [f"optim.max_iterations={int(gold['iterations'])}"] + extra)
+        attacker = breaching_amd.prepare_attack(case.model, case.loss_fn, cfg, dict(device=device, dtype=torch.float))
+        shared = [dict(gradients=list(d["gradients"]), buffers=d["buffers"], metadata=dict(d["metadata"])) for d in case.shared_data]
+        rec_models, labels, _ = attacker.prepare_attack(case.server_payload, shared)
+        for reg in attacker.regularizers:
+            reg.initialize(rec_models, shared, labels)
+        attacker.objective.initialize(attacker.loss_fn, cfg.impl, None)
+        attacker.objective.prepare(rec_models, shared)
+        xk = torch.as_tensor(gold["forced_x"][i]).to(device).clone().requires_grad_(True)
+        total, _ = attacker._autograd_objective([xk], labels, rec_models, shared, attacker.regularizers)
+        (g,) = torch.autograd.grad(total, [xk])
+        return cfg, labels, total.detach(), g.detach()
+
+    cfg, labels, total, g = hip_evaluation([])                                   # the timed path
+    _, _, total_ac, g_ac = hip_evaluation(["impl.fast_eval_bn=False"])           # kernels A and C on the stock BatchNorm modules
     control_model = copy.deepcopy(case.model).to(device).eval()
     xc = torch.as_tensor(gold["forced_x"][i]).to(device).clone().requires_grad_(True)
     task = case.loss_fn(control_model(xc), labels)
     rec_grads = torch.autograd.grad(task, tuple(control_model.parameters()), create_graph=True)
-    control_total = restate.gradient_objective("cosine-similarity", rec_grads, [g.to(device) for g in case.shared_data[0]["gradients"]], cfg.objective)
+    control_total = restate.gradient_objective("cosine-similarity", rec_grads, [t.to(device) for t in case.shared_data[0]["gradients"]], cfg.objective)
     control_total = control_total + restate.total_variation(xc, **cfg.regularization["total_variation"])
     (gc,) = torch.autograd.grad(control_total, [xc])
-    control_same = (torch.sign(gc.detach().cpu()) == sign_ref).double()
-    control_rel = abs(float(control_total) - want) / want
+    control = against_reference(control_total, gc)
+    control["what"] = ("the same evaluation on this GPU with PyTorch-ROCm ops only (oracle/restate.py statements, torch BatchNorm): the "
+                       "victim's convolutions as in the HIP path, no kernel of libbreach_hip.so")
+    kernels_ac = against_reference(total_ac, g_ac)
+    kernels_ac.update(what="kernel A (behind the double backward) + kernel C on the stock BatchNorm modules (impl.fast_eval_bn=False): the control's "
+                           "victim arithmetic, so the difference to the control is the attack-side kernels' own",
+                      loss_vs_control_rel=abs(float(total_ac) - float(control_total)) / abs(float(control_total)),
+                      sign_agreement_vs_control=float((torch.sign(g_ac.cpu()) == torch.sign(gc.detach().cpu())).double().mean()),
+                      tolerance_vs_control=1e-4)
+    sensitivity = float(gold["forced_sensitivity"][i])
+    ref_psnr = np.concatenate([[gold["psnr"]], gold["twin_psnr"]])
+    timed = against_reference(total, g)
     out = dict(fixture="tests/golden/attack_resnet18_24k.npz (unmodified reference on CPU, 24 000 iterations)", iterate=k,
-               loss_reference=want, loss_hip=float(total), loss_rel_err=abs(float(total) - want) / want,
-               loss_tolerance=max(1e-4, 3.0 * control_rel),
-               control=dict(what="the same evaluation on this GPU with PyTorch-ROCm ops only (oracle/restate.py statements, torch BatchNorm): "
-                                 "same victim convolutions as the HIP path, no kernel of libbreach_hip.so",
-                            loss=float(control_total), loss_rel_err=control_rel, sign_agreement=float(control_same.mean()),
-                            weighted_sign_agreement=float((control_same * weight).sum() / weight.sum()),
-                            sign_agreement_hip_vs_control=float((torch.sign(g) == torch.sign(gc.detach().cpu())).double().mean())),
-               loss_hip_vs_control_rel=abs(float(total) - float(control_total)) / abs(float(control_total)),
-               kink_sensitivity_recorded=float(gold["forced_sensitivity"][i]),
-               sign_agreement=float(same.mean()), reference_twin_agreement=float(gold["forced_twin_sign_agreement"][i]),
-               weighted_sign_agreement=float((same * weight).sum() / weight.sum()),
+               loss_reference=want, loss_hip=timed["loss"], loss_rel_err=timed["loss_rel_err"],
+               loss_tolerance=max(1e-4, 3.0 * control["loss_rel_err"], 3.0 * sensitivity),
+               loss_tolerance_is="max(1e-4, 3 x control.loss_rel_err, 3 x kink_sensitivity_recorded): the timed path includes kernel E's BatchNorm, "
+                                 "one rounding away from torch's -- an ulp-level perturbation of the activations, which is what the sensitivity measures",
+               control=control, kernels_A_C=kernels_ac,
+               loss_hip_vs_control_rel=abs(timed["loss"] - float(control_total)) / abs(float(control_total)),
+               kink_sensitivity_recorded=sensitivity,
+               sign_agreement=timed["sign_agreement"], reference_twin_agreement=float(gold["forced_twin_sign_agreement"][i]),
+               weighted_sign_agreement=timed["weighted_sign_agreement"],
                reference_twin_weighted_agreement=float(gold["forced_twin_weighted_sign_agreement"][i]),
                psnr_db_reference_runs=dict(mean=round(float(ref_psnr.mean()), 4), n=int(len(ref_psnr))))
-    out["ok"] = bool(out["loss_rel_err"] <= out["loss_tolerance"] and
-                     1 - out["sign_agreement"] <= 3 * (1 - out["reference_twin_agreement"]) + 1e-3)
+    out["ok"] = bool(out["loss_rel_err"] <= out["loss_tolerance"] and kernels_ac["loss_vs_control_rel"] <= kernels_ac["tolerance_vs_control"]
+                     and kernels_ac["loss_rel_err"] <= max(1e-4, 3.0 * control["loss_rel_err"])
+                     and 1 - out["sign_agreement"] <= 3 * (1 - out["reference_twin_agreement"]) + 1e-3)
     hip_runs = os.path.join(ROOT, "profiles", "r5_config1_24k_8starts.json")  # free-running HIP runs of the full horizon (committed)
     if os.path.exists(hip_runs):
         try:

@@ -10,7 +10,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 from . import build as _build
 
 # ---- constants mirrored from include/breach_hip.h (checked against the library in tests) -------------------------
-BH_ABI_VERSION = 6
+BH_ABI_VERSION = 7
 BH_GM_CHUNK = 4096
 BH_GM_MAX_PTRS = 448
 BH_GM_PARTIAL_STRIDE = 4
@@ -76,6 +76,14 @@ class StepParams(Structure):
         ("langevin", c_float),
         ("grad_clip", c_float),
     ]
+
+
+BH_STEP_MAX_SLOTS = 4
+
+
+class StepSlot(Structure):  # bh_step_slot: one optimised tensor of a list launch (include/breach_hip.h)
+    _fields_ = [("params", StepParams), ("x", c_void_p), ("g", c_void_p), ("g_reg", c_void_p), ("noise", c_void_p), ("m", c_void_p),
+                ("v", c_void_p), ("best", c_void_p)]
 
 
 _PROTOTYPES = {
@@ -156,6 +164,9 @@ _PROTOTYPES = {
     "bh_state_reset": (c_int, [c_void_p, c_void_p]),
     "bh_loss_commit": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "bh_grad_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p]),
+    "bh_step_list_norm_rows": (c_int32, [c_int32, POINTER(StepSlot)]),
+    "bh_grad_norm_list": (c_int, [c_void_p, c_int32, POINTER(StepSlot), c_void_p, c_void_p, c_void_p]),
+    "bh_candidate_step_list": (c_int, [c_void_p, c_void_p, c_int32, POINTER(StepSlot), c_void_p, c_void_p]),
     "bh_candidate_step": (
         c_int,
         [c_void_p, c_void_p, POINTER(StepParams), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -977,6 +977,7 @@ class FusedTrial:
         self.state = torch.zeros(_lib.BH_STATE_WORDS, dtype=torch.int32, device=device)
         self.history = torch.zeros(self.max_iterations, dtype=torch.float32, device=device)
         self.norm_ws = torch.empty(_lib.BH_PRIOR_MAX_GRID, dtype=torch.float64, device=device)
+        self.list_norm_ws = None  # partial rows of the per-tensor gradient norms of a multi-tensor (joint) attack, sized on first use
 
         self.fused_terms, self.autograd_regs = attacker._split_regularizers()
         first = self.candidates[0]
@@ -1122,6 +1123,34 @@ class FusedTrial:
                                    _lib.ptr(objective_value), _lib.ptr(self.prior_partials), n_reg, None, None, stream),
                 "bh_loss_commit",
             )
+            if len(self.slots) > 1:
+                # Joint data + label attack (optimization_with_label_attack.py:177-190): noise, clipping by each tensor's OWN norm,
+                # sign and the Adam step of ALL optimised tensors in ONE sum-of-squares launch and ONE kernel-B launch (SURVEY
+                # section 8 a17: "kernel B launched over a 2-tensor list"; round 5: three launches per tensor).
+                entries = (_lib.StepSlot * len(self.slots))()
+                keep = []  # the operands of the launches, alive until they are enqueued
+                for idx, (slot, grad) in enumerate(zip(self.slots, grads)):
+                    grad = grad.contiguous()
+                    reg_grad = self.prior_grad if (self.use_prior and idx == 0) else None
+                    noise = None
+                    if self.langevin > 0:  # :177-180, tensor by tensor like the reference's loop
+                        noise = torch.randn(grad.shape, dtype=grad.dtype).to(grad.device) if self.host_noise else torch.randn_like(grad)
+                    keep.append((grad, noise))
+                    entry = entries[idx]
+                    entry.params = slot["P"]
+                    entry.x, entry.g, entry.g_reg, entry.noise = slot["x"].data_ptr(), grad.data_ptr(), _lib.ptr(reg_grad).value, _lib.ptr(noise).value
+                    entry.m, entry.v, entry.best = slot["m"].data_ptr(), slot["v"].data_ptr(), slot["best"].data_ptr()
+                if self.grad_clip is not None:
+                    if self.list_norm_ws is None:
+                        rows = lib.bh_step_list_norm_rows(len(self.slots), entries)
+                        _lib.check(min(rows, 0), "bh_step_list_norm_rows")
+                        self.list_norm_ws = torch.empty(max(rows, 1), dtype=torch.float64, device=device)
+                    _lib.check(lib.bh_grad_norm_list(_lib.ptr(self.state), len(self.slots), entries, _lib.ptr(self.sched_dev),
+                                                     _lib.ptr(self.list_norm_ws), stream), "bh_grad_norm_list")
+                _lib.check(lib.bh_candidate_step_list(_lib.ptr(self.state), _lib.ptr(self.sched_dev), len(self.slots), entries,
+                                                      _lib.ptr(self.list_norm_ws), stream), "bh_candidate_step_list")
+                att.current_task_loss = task_loss
+                return
             for idx, (slot, grad) in enumerate(zip(self.slots, grads)):
                 grad = grad.contiguous()
                 reg_grad = self.prior_grad if (self.use_prior and idx == 0) else None

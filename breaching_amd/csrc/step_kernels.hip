@@ -108,8 +108,10 @@ struct StepScalars {
   bool improved;
 };
 
+// `gnorm_in`: the gradient norm of THIS tensor when the caller has it already (the list kernel derives it from the partial rows in
+// its preamble); NaN-free sentinel < 0 = read state[BH_STATE_GNORM] (the single-tensor launch behind bh_grad_norm).
 __device__ __forceinline__ StepScalars step_scalars(const Word* __restrict__ st, const double* __restrict__ sched,
-                                                    const bh_step_params& P, bool has_noise) {
+                                                    const bh_step_params& P, bool has_noise, float gnorm_in = -1.f) {
   StepScalars k;
   const int it = st[BH_STATE_IT].i;
   k.improved = st[BH_STATE_IMPROVED].i != 0;
@@ -120,7 +122,7 @@ __device__ __forceinline__ StepScalars step_scalars(const Word* __restrict__ st,
   k.noise_coef = has_noise ? (float)((double)P.langevin * row[3]) : 0.f;
   k.clip_mul = 1.f;
   if (P.grad_clip >= 0.f) {  // negative: clipping off (optim.grad_clip = None)
-    const float gn = st[BH_STATE_GNORM].f;
+    const float gn = gnorm_in >= 0.f ? gnorm_in : st[BH_STATE_GNORM].f;
     if (gn > P.grad_clip) k.clip_mul = P.grad_clip / (gn + 1e-6f);  // :173-174
   }
   // soft sign factor (:176-180): python evaluates 1 - iteration / max_iterations in double
@@ -229,6 +231,157 @@ __global__ __launch_bounds__(kBlock) void candidate_step_vec4_kernel(const Word*
   }
 }
 
+
+// ---- the same two stages over a LIST of optimised tensors (joint data + label attack: 2 tensors) in ONE launch each -------------
+// reference: optimization_with_label_attack.py:124-128 (only the data tensor is projected), :177-190 (noise, clip and sign applied to
+// `[candidate, labels]` tensor by tensor, each clipped by ITS OWN norm).  Round 5 launched kernel B, the sum of squares and its
+// finalize once per tensor: six latency-bound launches per iteration where two do.  The workgroups of a launch are dealt over the
+// slots (`first_block`); inside a slot the arithmetic is the single-tensor kernels', statement for statement:
+//   * sum of squares: slot s gets the SAME rows = min(ceil(n / 2048), BH_PRIOR_MAX_GRID) partial rows the single-tensor launch would use;
+//   * step: every workgroup first adds its slot's rows in the order grad_norm_finalize_kernel adds them (thread t: rows t, t + 256,
+//     ...; then the block sum) -- the rows are constants of this launch, so no workgroup waits for another, no ticket, no atomic --
+//     and workgroup 0 of the slot publishes the norm in state[BH_STATE_GNORM + s].  Bit-identical to the per-tensor launches.
+struct StepList {
+  bh_step_slot slot[BH_STEP_MAX_SLOTS];
+  int32_t first_block[BH_STEP_MAX_SLOTS + 1];  // workgroups [first_block[s], first_block[s + 1]) work on slot s
+  int32_t row_begin[BH_STEP_MAX_SLOTS + 1];    // partial rows of slot s in the norm workspace
+  int32_t n_slots;
+};
+
+__device__ __forceinline__ int slot_of_block(const StepList& L, int block) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < BH_STEP_MAX_SLOTS; ++k)
+    if (k < L.n_slots && block >= L.first_block[k]) s = k;
+  return s;
+}
+
+__global__ __launch_bounds__(kBlock) void grad_sumsq_list_kernel(const Word* __restrict__ st, StepList L,
+                                                                 const double* __restrict__ sched, double* __restrict__ ws) {
+  __shared__ double lds[bh::kWavesPerBlock];
+  const int s = slot_of_block(L, blockIdx.x);
+  const bh_step_slot& S = L.slot[s];
+  const int row = blockIdx.x - L.first_block[s], rows = L.first_block[s + 1] - L.first_block[s];
+  const int it = st[BH_STATE_IT].i;
+  const float noise_coef = S.noise ? (float)((double)S.params.langevin * sched[(int64_t)it * BH_SCHED_STRIDE + 3]) : 0.f;
+  float acc = 0.f;
+  double dacc = 0.0;
+  int cnt = 0;
+  for (int64_t i = (int64_t)row * kBlock + threadIdx.x; i < S.params.n; i += (int64_t)rows * kBlock) {
+    const float v = effective_grad(S.g, S.g_reg, S.noise, noise_coef, i);
+    acc = fmaf(v, v, acc);
+    if (++cnt == 32) {
+      dacc += (double)acc;
+      acc = 0.f;
+      cnt = 0;
+    }
+  }
+  double v[1] = {dacc + (double)acc};
+  bh::block_sum<1>(v, lds);
+  if (threadIdx.x == 0) ws[L.row_begin[s] + row] = v[0];
+}
+
+__global__ __launch_bounds__(kBlock) void candidate_step_list_kernel(Word* __restrict__ st, const double* __restrict__ sched,
+                                                                     StepList L, const double* __restrict__ ws) {
+  __shared__ double lds[bh::kWavesPerBlock];
+  __shared__ float gnorm_lds;
+  const int s = slot_of_block(L, blockIdx.x);
+  const bh_step_slot& S = L.slot[s];
+  const bh_step_params& P = S.params;
+  const int local = blockIdx.x - L.first_block[s], blocks = L.first_block[s + 1] - L.first_block[s];
+  float gn = -1.f;
+  if (P.grad_clip >= 0.f) {  // uniform per workgroup: every thread takes the barriers
+    double v[1] = {0.0};
+    for (int i = L.row_begin[s] + (int)threadIdx.x; i < L.row_begin[s + 1]; i += kBlock) v[0] += ws[i];  // grad_norm_finalize_kernel's order
+    bh::block_sum<1>(v, lds);
+    if (threadIdx.x == 0) gnorm_lds = (float)sqrt(v[0]);
+    __syncthreads();
+    gn = gnorm_lds;
+    if (local == 0 && threadIdx.x == 0) st[BH_STATE_GNORM + s].f = gn;  // for observers; nothing in this launch reads it
+  }
+  const StepScalars k = step_scalars(st, sched, P, S.noise != nullptr, gn);
+  const uintptr_t align = reinterpret_cast<uintptr_t>(S.x) | reinterpret_cast<uintptr_t>(S.g) | reinterpret_cast<uintptr_t>(S.m) |
+                          reinterpret_cast<uintptr_t>(S.v) | reinterpret_cast<uintptr_t>(S.best);
+  const bool vec4 = S.g_reg == nullptr && S.noise == nullptr && (P.n & 3) == 0 && (align & 15u) == 0 && (!P.boxed || (P.plane & 3) == 0);
+  if (vec4) {  // candidate_step_vec4_kernel<false, false>'s body
+    const int64_t n4 = P.n >> 2, plane4 = P.plane >> 2;
+    float4* __restrict__ x4 = reinterpret_cast<float4*>(S.x);
+    float4* __restrict__ m4 = reinterpret_cast<float4*>(S.m);
+    float4* __restrict__ v4 = reinterpret_cast<float4*>(S.v);
+    float4* __restrict__ b4 = reinterpret_cast<float4*>(S.best);
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(S.g);
+    for (int64_t i = (int64_t)local * kBlock + threadIdx.x; i < n4; i += (int64_t)blocks * kBlock) {
+      const float4 gv = g4[i];
+      float4 xv = x4[i], mv = m4[i], vv = v4[i];
+      const int c = P.boxed ? (int)((i / plane4) % P.channels) : 0;
+      const float lo = P.lo[c], hi = P.hi[c];
+      step_elem(k, P, gv.x, lo, hi, xv.x, mv.x, vv.x);
+      step_elem(k, P, gv.y, lo, hi, xv.y, mv.y, vv.y);
+      step_elem(k, P, gv.z, lo, hi, xv.z, mv.z, vv.z);
+      step_elem(k, P, gv.w, lo, hi, xv.w, mv.w, vv.w);
+      x4[i] = xv;
+      m4[i] = mv;
+      v4[i] = vv;
+      if (k.improved) b4[i] = xv;
+    }
+  } else {  // candidate_step_kernel's body
+    for (int64_t i = (int64_t)local * kBlock + threadIdx.x; i < P.n; i += (int64_t)blocks * kBlock) {
+      const float gr = effective_grad(S.g, S.g_reg, S.noise, k.noise_coef, i);
+      float xi = S.x[i], mi = S.m[i], vi = S.v[i];
+      const int c = P.boxed ? (int)((i / P.plane) % P.channels) : 0;
+      step_elem(k, P, gr, P.lo[c], P.hi[c], xi, mi, vi);
+      S.x[i] = xi;
+      S.m[i] = mi;
+      S.v[i] = vi;
+      if (k.improved) S.best[i] = xi;
+    }
+  }
+}
+
+int step_slot_ok(const bh_step_slot& S) {
+  const bh_step_params& P = S.params;
+  if (S.x == nullptr || S.g == nullptr || S.m == nullptr || S.v == nullptr || S.best == nullptr) return 0;
+  if (P.n <= 0 || P.max_iterations <= 0) return 0;
+  if (P.boxed && (P.channels <= 0 || P.channels > 4 || P.plane <= 0)) return 0;
+  if (P.langevin > 0.f && S.noise == nullptr) return 0;
+  if (P.sign_mode < BH_SIGN_NONE || P.sign_mode > BH_SIGN_SOFT) return 0;
+  return 1;
+}
+
+int norm_rows(int64_t n) {  // bh_grad_norm's grid
+  int64_t blocks = (n + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8);
+  if (blocks > BH_PRIOR_MAX_GRID) blocks = BH_PRIOR_MAX_GRID;
+  return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// Fills L from the caller's slots; returns 0 or BH_EINVAL.  `for_norm`: workgroups = partial rows; else kernel B's grid per slot.
+int build_step_list(int32_t n_slots, const bh_step_slot* slots, bool for_norm, StepList& L) {
+  if (slots == nullptr || n_slots <= 0 || n_slots > BH_STEP_MAX_SLOTS) return BH_EINVAL;
+  L.n_slots = n_slots;
+  L.first_block[0] = L.row_begin[0] = 0;
+  for (int s = 0; s < BH_STEP_MAX_SLOTS; ++s) {
+    if (s < n_slots) {
+      if (!step_slot_ok(slots[s])) return BH_EINVAL;
+      L.slot[s] = slots[s];
+      if (L.slot[s].params.langevin <= 0.f) L.slot[s].noise = nullptr;
+      const bh_step_params& P = slots[s].params;
+      const int rows = P.grad_clip >= 0.f ? norm_rows(P.n) : 0;  // a slot without clipping has no rows and no norm workgroups
+      int64_t blocks = rows;
+      if (!for_norm) {
+        const bool quads = (P.n & 3) == 0;  // upper bound of the workgroups the slot can use; the kernel re-derives the access width
+        blocks = ((quads ? P.n >> 2 : P.n) + kBlock - 1) / kBlock;
+        if (blocks > 2048) blocks = 2048;
+      }
+      L.first_block[s + 1] = L.first_block[s] + (int)blocks;
+      L.row_begin[s + 1] = L.row_begin[s] + rows;
+    } else {
+      L.first_block[s + 1] = L.first_block[s];
+      L.row_begin[s + 1] = L.row_begin[s];
+    }
+  }
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -297,6 +450,37 @@ int bh_candidate_step(const void* state_dev, const double* sched_dev, const bh_s
     hipLaunchKernelGGL(candidate_step_kernel, dim3((int)blocks), dim3(kBlock), 0, bh::as_stream(stream),
                        static_cast<const Word*>(state_dev), sched_dev, P, x, g, g_reg, noise, m, v,
                        best);
+  return bh::launch_status();
+}
+
+int32_t bh_step_list_norm_rows(int32_t n_slots, const bh_step_slot* slots) {
+  StepList L;
+  const int rc = build_step_list(n_slots, slots, true, L);
+  return rc != 0 ? rc : L.row_begin[BH_STEP_MAX_SLOTS];
+}
+
+int bh_grad_norm_list(const void* state_dev, int32_t n_slots, const bh_step_slot* slots, const double* sched_dev, double* ws_dev,
+                      void* stream) {
+  StepList L;
+  const int rc = build_step_list(n_slots, slots, true, L);
+  if (rc != 0) return rc;
+  if (state_dev == nullptr || sched_dev == nullptr) return BH_EINVAL;
+  const int grid = L.first_block[BH_STEP_MAX_SLOTS];
+  if (grid == 0) return 0;  // no slot clips: nothing to launch
+  if (ws_dev == nullptr) return BH_EINVAL;
+  hipLaunchKernelGGL(grad_sumsq_list_kernel, dim3(grid), dim3(kBlock), 0, bh::as_stream(stream), static_cast<const Word*>(state_dev), L,
+                     sched_dev, ws_dev);
+  return bh::launch_status();
+}
+
+int bh_candidate_step_list(void* state_dev, const double* sched_dev, int32_t n_slots, const bh_step_slot* slots, const double* ws_dev,
+                           void* stream) {
+  StepList L;
+  const int rc = build_step_list(n_slots, slots, false, L);
+  if (rc != 0) return rc;
+  if (state_dev == nullptr || sched_dev == nullptr || (L.row_begin[BH_STEP_MAX_SLOTS] > 0 && ws_dev == nullptr)) return BH_EINVAL;
+  hipLaunchKernelGGL(candidate_step_list_kernel, dim3(L.first_block[BH_STEP_MAX_SLOTS]), dim3(kBlock), 0, bh::as_stream(stream),
+                     static_cast<Word*>(state_dev), sched_dev, L, ws_dev);
   return bh::launch_status();
 }
 

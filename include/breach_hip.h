@@ -28,7 +28,7 @@ extern "C" {
 /* 6: multi-tensor launch groups are BH_MT_MAX_PTRS = 112 tensors (two adjacent groups per launch for the forms with at most two
  *    pointer lists), bh_mt_* write outputs larger than the Infinity Cache with non-temporal stores; 5: tuning knobs became launch
  *    arguments (no mutable library state). */
-#define BH_ABI_VERSION 6
+#define BH_ABI_VERSION 7
 #define BH_EINVAL (-1)
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -388,7 +388,8 @@ enum bh_state_word {
   BH_STATE_IMPROVED = 3,  /* int32: 1 when this iteration's objective beat the best so far */
   BH_STATE_MIN = 4,       /* fp32: minimal objective so far (+inf initially) */
   BH_STATE_TOTAL = 5,     /* fp32: total objective of this iteration */
-  BH_STATE_GNORM = 6,     /* fp32: L2 norm of the (noise-perturbed) candidate gradient, when clipping */
+  BH_STATE_GNORM = 6,     /* fp32: L2 norm of the (noise-perturbed) candidate gradient, when clipping; words 6 .. 6 +
+                           * BH_STEP_MAX_SLOTS - 1: one per slot of the list launches (bh_candidate_step_list) */
   BH_STATE_WORDS = 16
 };
 
@@ -435,6 +436,34 @@ typedef struct bh_step_params {
 int bh_candidate_step(const void* state_dev, const double* sched_dev, const bh_step_params* params, float* x,
                       const float* g, const float* g_reg, const float* noise, float* m, float* v, float* best,
                       void* stream);
+
+/* The same two stages over a LIST of optimised tensors, ONE launch each (ABI 7) -- the joint data + label attack optimises
+ * `[candidate, labels]` and applies noise, clipping (each tensor by ITS OWN norm), sign and the Adam step tensor by tensor,
+ * projecting only the data tensor: optimization_with_label_attack.py:124-128, :177-190.  A slot = one tensor with its own
+ * bh_step_params (box, clip threshold, ...) and buffers; <= BH_STEP_MAX_SLOTS slots travel in the kernel-argument segment.
+ *   bh_grad_norm_list:      per-slot partial sums of squares of the effective gradient into ws_dev -- slot s owns
+ *                           min(ceil(n_s / 2048), BH_PRIOR_MAX_GRID) rows (bh_grad_norm's own grid), slots without clipping none;
+ *                           ws_dev holds bh_step_list_norm_rows(...) doubles.  No launch when no slot clips.
+ *   bh_candidate_step_list: every workgroup adds its slot's rows in bh_grad_norm's finalize order (constants of the launch: no
+ *                           ticket, no atomic), then runs bh_candidate_step's arithmetic on its share of the slot; the norm of
+ *                           slot s is also left in state[BH_STATE_GNORM + s].  Bit-identical to per-tensor launches of
+ *                           bh_grad_norm + bh_candidate_step. */
+#define BH_STEP_MAX_SLOTS 4
+typedef struct bh_step_slot {
+  bh_step_params params;
+  float* x;
+  const float* g;
+  const float* g_reg; /* may be NULL */
+  const float* noise; /* may be NULL unless params.langevin > 0 */
+  float* m;
+  float* v;
+  float* best;
+} bh_step_slot;
+int32_t bh_step_list_norm_rows(int32_t n_slots, const bh_step_slot* slots);
+int bh_grad_norm_list(const void* state_dev, int32_t n_slots, const bh_step_slot* slots, const double* sched_dev, double* ws_dev,
+                      void* stream);
+int bh_candidate_step_list(void* state_dev, const double* sched_dev, int32_t n_slots, const bh_step_slot* slots, const double* ws_dev,
+                           void* stream);
 
 /* Timing helpers (thin wrappers over hipEvent*, used by bench.py for the roofline leg). */
 int bh_event_create(void** event_out);

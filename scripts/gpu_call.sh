@@ -77,5 +77,23 @@ stepprior_trace() {
 }
 mt_trace() { prof 200 mt_kernel_probe "" python $GRAFT_REPO_ROOT/scripts/mt_kernel_probe.py --launches 20; }
 
+# ---- round 6 ----
+affine()   {  # kernel E layer by layer at B = 8: rocprofv3 kernel trace of scripts/affine_layer_probe.py joined with its manifest
+  rm -rf /tmp/prof_${TAG}_affine
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_affine -- python $GRAFT_REPO_ROOT/scripts/affine_layer_probe.py --manifest $OUT/${TAG}_affine_layer_manifest.json > $OUT/${TAG}_affine_stdout.log 2> $OUT/${TAG}_affine_stderr.log)
+  trace=$(ls -S $(find /tmp/prof_${TAG}_affine -name "*kernel_trace.csv") | head -1)
+  [ -n "$trace" ] && python scripts/affine_layer_probe.py --join $trace --manifest $OUT/${TAG}_affine_layer_manifest.json --out $OUT/${TAG}_affine_layers 2>&1 | cut -c1-900
+  tail -2 $OUT/${TAG}_affine_stderr.log | cut -c1-300
+}
+pool8()    { timeout 900 $B --restarts32-pool 8 --restarts32-iters ${POOL_ITERS:-100} > $OUT/${TAG}_restarts32_pool8_one_gpu.json 2> $OUT/${TAG}_restarts32_pool8_one_gpu.err; tail -1 $OUT/${TAG}_restarts32_pool8_one_gpu.json | cut -c1-1500; tail -3 $OUT/${TAG}_restarts32_pool8_one_gpu.err | cut -c1-300; }
+pool2()    { timeout 900 $B --restarts32-pool 2 --restarts32-iters ${POOL_ITERS:-1000} > $OUT/${TAG}_restarts32_pool2_one_gpu.json 2> $OUT/${TAG}_restarts32_pool2_one_gpu.err; tail -1 $OUT/${TAG}_restarts32_pool2_one_gpu.json | cut -c1-1500; tail -3 $OUT/${TAG}_restarts32_pool2_one_gpu.err | cut -c1-300; }
+batched()  {  # trial batching decided with a number: vmap(grad) over K restarts in one victim pass vs 4 in flight (553 it/s)
+  for k in 4 8 16; do
+    timeout 300 python scripts/batched_restarts_probe.py --trials $k --steps 40 --only batched >> $OUT/${TAG}_batched_restarts_probe.jsonl 2>> $OUT/${TAG}_batched_restarts_probe.err
+  done
+  timeout 300 python scripts/batched_restarts_probe.py --trials 8 --steps 40 --only batched --groups 2 >> $OUT/${TAG}_batched_restarts_probe.jsonl 2>> $OUT/${TAG}_batched_restarts_probe.err
+  cut -c1-400 $OUT/${TAG}_batched_restarts_probe.jsonl; tail -2 $OUT/${TAG}_batched_restarts_probe.err | cut -c1-300
+}
+
 set -x
 for stage in "$@"; do $stage; done

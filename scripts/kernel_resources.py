@@ -14,8 +14,8 @@ nothing on this path is GEMM-shaped).
 in a kernel that runs thousands of wavefronts, the whole cost of one that runs a wavefront per SIMD (how kernels E and F
 were found in round 4).
 
-    python scripts/kernel_resources.py [--out profiles/r5_kernel_resources.txt] [--isa --isa-out profiles/r5_kernel_isa_census.txt]
-                                       [--loops --loops-out profiles/r5_kernel_loop_census.txt]
+    python scripts/kernel_resources.py [--out profiles/kernel_resources.txt] [--isa --isa-out profiles/kernel_isa_census.txt]
+                                       [--loops --loops-out profiles/kernel_loop_census.txt]
 """
 import argparse
 import os

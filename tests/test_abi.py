@@ -88,6 +88,7 @@ def test_chunk_table_host_helpers(hip_lib):
     assert hip_lib.bh_gm_fwd(99, 1, None, None, None, 1, None, None, 0.0, None, 0, 0, None, None, None) == -1
     assert hip_lib.bh_gm_fwd(0, 1, None, None, None, 1, None, None, 0.0, None, 0, 7, None, None, None) == -1  # unknown cache policy
     assert hip_lib.bh_candidate_step(None, None, None, None, None, None, None, None, None, None, None) == -1
+    assert hip_lib.bh_candidate_step_list(None, None, 1, None, None, None) == -1 and hip_lib.bh_step_list_norm_rows(1, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
@@ -121,7 +122,7 @@ def test_header_is_valid_c99(tmp_path):
 
 
 @pytest.mark.parametrize("c_name,mirror", [("bh_step_params", "StepParams"), ("bh_gm_chunk", "GmChunk"),
-                                           ("bh_bn_layer", "BnLayer"), ("bh_bn_item", "BnItem")])
+                                           ("bh_bn_layer", "BnLayer"), ("bh_bn_item", "BnItem"), ("bh_step_slot", "StepSlot")])
 def test_struct_layouts_match_ctypes(tmp_path, c_name, mirror):
     """sizeof / offsetof of every ABI struct as the C compiler sees them == its ctypes mirror in _lib."""
     import subprocess
@@ -353,7 +354,7 @@ def test_static_kernel_resources_no_scratch_and_full_occupancy_for_the_streaming
     # small, latency-bound: DESIGN.md names them (tv_norm_vec4: four pixels x three planes x ten neighbours live per lane)
     # kernel B's 16-byte variant with the noise operand: six float4 operands + four results live per lane, 66-71 VGPRs = 7 waves
     assert exceptions == ["bn_finalize_kernel", "candidate_step_vec4_kernel", "tv_norm_kernel", "tv_norm_vec4_kernel"], exceptions
-    _assert_matches_committed_table(root, "r5_kernel_resources.txt", kernel_resources.render(rows))
+    _assert_matches_committed_table(root, "kernel_resources.txt", kernel_resources.render(rows))
 
 
 def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
@@ -397,7 +398,7 @@ def test_instruction_census_16_byte_accesses_cache_policy_bits_and_no_mfma():
         if m:
             assert row["ld_nt"] == (row["ld128"] if m.group(2) == "true" else 0), (name, row)
             assert (row["st_nt"] > 0) == (m.group(3) == "true"), (name, row)
-    _assert_matches_committed_table(root, "r5_kernel_isa_census.txt", kernel_resources.render_isa(census))
+    _assert_matches_committed_table(root, "kernel_isa_census.txt", kernel_resources.render_isa(census))
 
 
 def test_loop_census_kernels_e_and_f_keep_several_loads_in_flight_per_trip():
@@ -423,4 +424,4 @@ def test_loop_census_kernels_e_and_f_keep_several_loads_in_flight_per_trip():
             assert r["loads"] >= 4, r
         if r["kernel"].startswith("gm_fwd_kernel"):
             assert r["loads"] >= 10 and r["full_waits"] <= 3, r  # kernel A forward: eight staged 16-byte loads per chunk (+ the chunk record)
-    _assert_matches_committed_table(root, "r5_kernel_loop_census.txt", kernel_resources.render_loops(rows))
+    _assert_matches_committed_table(root, "kernel_loop_census.txt", kernel_resources.render_loops(rows))

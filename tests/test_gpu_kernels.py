@@ -413,6 +413,84 @@ def test_candidate_step_16_byte_path_is_bit_identical_to_the_4_byte_path(sign_mo
     assert not torch.equal(vec[0], vec[3])  # the third loss (2.5) did not improve: best kept the second iterate
 
 
+@pytest.mark.parametrize("langevin,clips", [(0.0, (1.0, 1.0)), (0.01, (1.0, -1.0)), (0.0, (-1.0, -1.0)), (0.0, (0.0, 2.5))])
+def test_list_launches_are_bit_identical_to_per_tensor_launches(langevin, clips, hip_lib):
+    """The joint data + label attack (optimization_with_label_attack.py:124-128, :177-190) steps `[candidate, labels]`: ONE
+    `bh_grad_norm_list` + ONE `bh_candidate_step_list` launch over the two tensors against round 5's per-tensor sequence
+    (bh_grad_norm + bh_candidate_step each, themselves held to the C oracle by test_candidate_step_matches_c_oracle): x, m, v, best
+    and the per-slot norms bit for bit over four iterations.  Slot 0: TAG's embedding candidate, 16-byte path; slot 1: a label
+    tensor whose size is not a multiple of 4 (4-byte path), not boxed; per-slot clip thresholds incl. "off" and the legal 0."""
+    from breaching_amd import _lib, schedules
+
+    dev = _dev()
+    rng = np.random.default_rng(5)
+    shapes = [(1, 32, 768), (1, 32, 3001)]
+    table = schedules.adam_schedule_table(schedules.lr_sequence(0.1, "linear", 2, 8), 0.9, 0.999, 0.01)
+    sched = torch.from_numpy(table).to(dev)
+    stream = _lib.current_stream_handle(dev)
+
+    def params(shape, boxed, clip):
+        P = _lib.StepParams()
+        P.n, P.plane, P.channels, P.boxed, P.sign_mode, P.max_iterations = int(np.prod(shape)), int(np.prod(shape)), 1, int(boxed), 0, 8
+        P.lo[0], P.hi[0] = -1.5, 1.5
+        P.beta1, P.beta2, P.eps, P.decoupled_wd, P.langevin, P.grad_clip = 0.9, 0.999, 1e-6, 1, langevin, clip
+        return P
+
+    Ps = [params(shapes[0], True, clips[0]), params(shapes[1], False, clips[1])]
+    x0 = [torch.tensor(rng.standard_normal(s).astype(np.float32)) for s in shapes]
+    feed = [[dict(g=torch.tensor(rng.standard_normal(s).astype(np.float32) * 3.0).to(dev), noise=torch.tensor(rng.standard_normal(s).astype(np.float32)).to(dev))
+             for s in shapes] for _ in range(4)]
+    losses = [3.0, 2.0, 1.0, 2.5]
+
+    def run(as_list):
+        state = torch.zeros(_lib.BH_STATE_WORDS, dtype=torch.int32, device=dev)
+        history = torch.zeros(8, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.BH_PRIOR_MAX_GRID, dtype=torch.float64, device=dev)
+        bufs = [dict(x=x.clone().to(dev), m=torch.zeros(s, device=dev), v=torch.zeros(s, device=dev), best=x.clone().to(dev)) for x, s in zip(x0, shapes)]
+        norms = []
+        _lib.check(hip_lib.bh_state_reset(_lib.ptr(state), stream), "reset")
+        for it in range(4):
+            loss = torch.tensor([losses[it]], dtype=torch.float32, device=dev)
+            _lib.check(hip_lib.bh_loss_commit(_lib.ptr(state), _lib.ptr(history), 8, _lib.ptr(loss), None, 0, None, None, stream), "commit")
+            if as_list:
+                entries = (_lib.StepSlot * 2)()
+                for e, P, b, f in zip(entries, Ps, bufs, feed[it]):
+                    e.params = P
+                    e.x, e.g, e.g_reg, e.noise = b["x"].data_ptr(), f["g"].data_ptr(), None, (f["noise"].data_ptr() if langevin > 0 else None)
+                    e.m, e.v, e.best = b["m"].data_ptr(), b["v"].data_ptr(), b["best"].data_ptr()
+                rows = hip_lib.bh_step_list_norm_rows(2, entries)
+                assert rows == sum(min(-(-P.n // 2048), _lib.BH_PRIOR_MAX_GRID) for P in Ps if P.grad_clip >= 0)
+                _lib.check(hip_lib.bh_grad_norm_list(_lib.ptr(state), 2, entries, _lib.ptr(sched), _lib.ptr(ws), stream), "norm list")
+                _lib.check(hip_lib.bh_candidate_step_list(_lib.ptr(state), _lib.ptr(sched), 2, entries, _lib.ptr(ws), stream), "step list")
+                torch.cuda.synchronize()
+                host = state.cpu()
+                norms.append([host[_lib.STATE_GNORM + k : _lib.STATE_GNORM + k + 1].view(torch.float32).item() if Ps[k].grad_clip >= 0 else None for k in range(2)])
+            else:
+                per = []
+                for P, b, f in zip(Ps, bufs, feed[it]):
+                    noise = f["noise"] if langevin > 0 else None
+                    if P.grad_clip >= 0:
+                        _lib.check(hip_lib.bh_grad_norm(_lib.ptr(state), _lib.ptr(f["g"]), None, _lib.ptr(noise), P.n, _lib.ptr(sched), langevin, _lib.ptr(ws), stream), "norm")
+                    _lib.check(hip_lib.bh_candidate_step(_lib.ptr(state), _lib.ptr(sched), P, _lib.ptr(b["x"]), _lib.ptr(f["g"]), None, _lib.ptr(noise),
+                                                         _lib.ptr(b["m"]), _lib.ptr(b["v"]), _lib.ptr(b["best"]), stream), "step")
+                    torch.cuda.synchronize()
+                    per.append(state.cpu()[_lib.STATE_GNORM : _lib.STATE_GNORM + 1].view(torch.float32).item() if P.grad_clip >= 0 else None)
+                norms.append(per)
+        torch.cuda.synchronize()
+        return bufs, norms
+
+    (listed, norms_list), (single, norms_single) = run(True), run(False)
+    assert norms_list == norms_single
+    for k in range(2):
+        for name in ("x", "m", "v", "best"):
+            assert torch.equal(listed[k][name], single[k][name]), (k, name)
+        assert not torch.equal(listed[k]["x"], listed[k]["best"])  # the fourth loss did not improve: best kept the third iterate
+    # invalid lists are reported, not crashed on
+    entries = (_lib.StepSlot * 2)()
+    assert hip_lib.bh_candidate_step_list(None, None, 2, entries, None, None) == -1
+    assert hip_lib.bh_grad_norm_list(None, 5, entries, None, None, None) == -1 and hip_lib.bh_step_list_norm_rows(0, entries) == -1
+
+
 def test_candidate_step_best_copy_is_post_step_candidate(kernels_oracle, hip_lib):
     r = _step_once(hip_lib, (1, 3, 8, 8), 1, True, False, 0.0, -1.0, steps=4)
     # losses 3, 2, 2.5, 1 -> improvements at iterations 0, 1, 3 -> best == candidate after the 4th step
