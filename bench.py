@@ -575,7 +575,8 @@ def restarts32_pool_subprocess(ranks, iters, num_trials, model_name, timeout):
     cmd = [sys.executable, os.path.abspath(__file__), "--restarts32-pool", str(ranks), "--restarts32-iters", str(iters),
            "--restarts32-trials", str(num_trials), "--model", model_name]
     try:
-        env = dict(os.environ, BREACH_HIP_POOL_START_TIMEOUT=os.environ.get("BREACH_HIP_POOL_START_TIMEOUT", str(int(timeout * 0.5))))
+        env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_") and k not in ("OMP_NUM_THREADS",)}  # torchrun's: not this process's
+        env["BREACH_HIP_POOL_START_TIMEOUT"] = os.environ.get("BREACH_HIP_POOL_START_TIMEOUT", str(int(timeout * 0.5)))
         proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
         for text in reversed(proc.stdout.splitlines()):
             if text.startswith("{"):
@@ -639,7 +640,8 @@ def main():
     from breaching_amd.cases import build_case, initial_candidate
 
     if args.restarts32_pool > 1:  # the pool shape of the restarts32 leg alone (a process that owns its process group)
-        for key in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
+        for key in [k for k in os.environ if k.startswith("TORCHELASTIC_")] + ["WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                                "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME", "MASTER_ADDR", "MASTER_PORT"]:
             os.environ.pop(key, None)  # when started by a torch.distributed.run rank: this process is nobody's rank
         index = int(os.environ.get("BENCH_DEVICE_INDEX", "0"))
         torch.cuda.set_device(index)

@@ -638,6 +638,7 @@ class HipOptimizationAttacker:
                 if isinstance(module, _EvalAffineBatchNorm2d) and not module.training and module.running_var is not None:
                     module._frozen_statistics()
         main = torch.cuda.current_stream(device)
+        self._first_use_warm_up(rec_model, shared_data, labels, init_states[group[0]])
         # EVERY trial of the group gets a side stream of its own; none runs on the caller's stream.  Measured (round 3,
         # profiles/r3_stall_bisect.jsonl): once an earlier attack of the process has replayed a hipGraph on the caller's
         # stream (the legacy null stream in simulate_breach.py / benchmark_breaches.py), a group with one trial on that
@@ -692,6 +693,29 @@ class HipOptimizationAttacker:
             main.wait_stream(streams[t])
             solutions[t] = best[0] if len(best) == 1 else tuple(best)
         return solutions
+
+    def _first_use_warm_up(self, rec_model, shared_data, labels, init_state):
+        """Once per attacker and process, before its first group of concurrent trials: one throw-away evaluation of the objective
+        and its gradient on a copy of a starting point, on the caller's stream, then a device synchronisation.  Everything the
+        libraries underneath do on first use of this model -- MIOpen's solver selection and kernel compilation for every
+        convolution configuration of the three autograd orders, rocBLAS handles, lazily built plans -- is finished before four
+        trials start issuing the same work from four streams.  Seen without it (round 6, a fresh box, four worker processes sharing
+        one GPU): the FIRST trial of a worker's first group left its single-rank trajectory at iteration 1 in 2 of ~80 runs, by
+        7e-5 and by 16 %, every other trial bit-identical.  Costs one iteration; changes no trial (no RNG draw, no state)."""
+        if getattr(self, "_warmed_up", False):
+            return
+        scratch = [c.detach().clone().requires_grad_(True) for c in init_state]
+        _, autograd_regs = self._split_regularizers()
+        total, _ = self._autograd_objective(scratch, labels, rec_model, shared_data, autograd_regs)
+        if torch.is_tensor(total) and total.requires_grad:
+            torch.autograd.grad(total, scratch, allow_unused=True)
+        for reg in autograd_regs:  # nothing of this evaluation may stay alive (an autograd graph would block the hipGraph capture)
+            release = getattr(reg, "release_graph", None)
+            if release is not None:
+                release()
+        del total, scratch
+        torch.cuda.synchronize(self.setup["device"])
+        self._warmed_up = True
 
     def _record_execution(self, trial, mode):
         record = getattr(self, "_trial_execution", None)

@@ -343,6 +343,10 @@ class TrialWorkerPool:
             self.workers.append((proc, parent_end))
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(self.port)
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        # A process started by torch.distributed.run (a rank that left its group, or a tool run under torchrun) carries
+        # TORCHELASTIC_USE_AGENT_STORE=True: rank 0 would then CONNECT to the elastic agent's store instead of hosting this pool's own
+        # (round 6: the pool leg of `bench.py --gpus N` timed out in the rendezvous).  This group is the pool's, not the agent's.
+        os.environ.pop("TORCHELASTIC_USE_AGENT_STORE", None)
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", self.devices[0])

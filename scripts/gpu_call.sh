@@ -42,7 +42,7 @@ stepprior() {
 bench_driver() { timeout 600 $B --gpus 1 --steps 20 --warmup 5 > $OUT/${TAG}_bench_driver_style.json 2> $OUT/${TAG}_bench_driver_style.err; cut -c1-600 $OUT/${TAG}_bench_driver_style.json; tail -2 $OUT/${TAG}_bench_driver_style.err | cut -c1-300; }
 bench_n1()     { timeout 600 $B > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err; cut -c1-300 $OUT/${TAG}_bench_n1.json; }
 bench_4()      { timeout 600 $B --trials-per-gpu 4 --cpu-baseline-iters 0 --no-hbm-resident > $OUT/${TAG}_bench_n1_4trials_in_flight.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_n1_4trials_in_flight.json; }
-bench_8ranks() { timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 20 --warmup 5 > $OUT/${TAG}_bench_8ranks_one_gpu.json 2> $OUT/${TAG}_bench_8ranks_one_gpu.err; tail -1 $OUT/${TAG}_bench_8ranks_one_gpu.json | cut -c1-900; tail -3 $OUT/${TAG}_bench_8ranks_one_gpu.err | cut -c1-300; }
+bench_8ranks() { timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 20 --warmup 5 --restarts32-iters ${POOL_ITERS:-100} > $OUT/${TAG}_bench_8ranks_one_gpu.json 2> $OUT/${TAG}_bench_8ranks_one_gpu.err; tail -1 $OUT/${TAG}_bench_8ranks_one_gpu.json | cut -c1-900; tail -3 $OUT/${TAG}_bench_8ranks_one_gpu.err | cut -c1-300; }
 trace_bench()  {
   prof 400 bench "" $B --steps 100 --warmup 20 --cpu-baseline-iters 0 --gpu-torch-baseline-iters 0 --no-parity --no-span-timing --no-hbm-resident --no-dry-collective
   trace=$(ls -S $(find /tmp/prof_${TAG}_bench -name "*kernel_trace.csv") | head -1)

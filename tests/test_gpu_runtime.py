@@ -245,6 +245,28 @@ def test_bench_restarts_leg_through_the_worker_pool():
     assert pool["job_ship_s"] > 0 and pool["trials_wait_s"] >= 0 and pool["select_s"] > 0 and leg["warmup_pool"]["pool_start_s"] > 0
 
 
+def test_bench_multi_rank_launch_on_one_gpu():
+    """`python bench.py --gpus 2` end to end, as the driver's scaling run launches it (torch.distributed.run, one rank per "GPU"; here
+    both ranks on cuda:0 over gloo, `oversubscribed`): the staged start through rank 0's file flag (bounded -- no collective holds the
+    other ranks), the weak-scaling line, the selection collective, and then -- after the ranks have left -- BASELINE configs[3]
+    through the product's TrialWorkerPool in a bounded process of its own (`restarts32`, entry = TrialWorkerPool, 2 ranks)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--restarts32-iters", "8",
+           "--restarts32-trials", "8"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=1200, env=env)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{\"metric\"")]
+    assert len(lines) == 1, proc.stdout[-1500:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["oversubscribed"] is True and line["collective_backend"] == "gloo" and line["scaling"] == "weak"
+    assert line["value"] == pytest.approx(2 * 4 / (line["ms_per_step"] * 4e-3), rel=1e-3) and len(line["per_rank_ms_per_step"]) == 2
+    assert line["select_ms"] > 0 and line["score_ms"] > 0
+    staged = line["staged_start"]["ranks"]
+    assert [r["rank"] for r in staged] == [1] and staged[0]["released"] is True
+    _check_restarts_leg(line["restarts32"], trials=8, iters=8, ranks=2)
+    assert line["restarts32"]["entry"].startswith("TrialWorkerPool") and line["restarts32"]["pool"]["world"] == 2
+
+
 def test_graph_capture_with_a_live_rccl_process_group():
     """What every rank of the multi-GPU path does and a 1-GPU box had never done IN ONE PROCESS: capture the attack iteration into a
     hipGraph while an RCCL ("nccl") process group is alive -- its watchdog thread polls events in the background, which a capture in

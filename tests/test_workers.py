@@ -96,7 +96,7 @@ def test_pool_runs_jobs_selects_and_survives_errors():
     assert workers.active_pool() is None and not dist.is_initialized()  # the group never outlives its pool
 
 
-def test_pool_start_fails_fast_when_a_child_cannot_boot_and_pool_dies_with_its_owner():
+def test_pool_start_fails_fast_when_a_child_cannot_boot_and_pool_dies_with_its_owner(monkeypatch):
     """A child whose arguments do not unpickle (an unimportable victim model class) is noticed through `is_alive` within
     seconds, not after the rendezvous timeout; the module-level handle on the active pool is weak."""
     import gc
@@ -113,6 +113,9 @@ def test_pool_start_fails_fast_when_a_child_cannot_boot_and_pool_dies_with_its_o
     assert time.time() - t0 < 60.0
     assert workers.active_pool() is None and not dist.is_initialized()
 
+    # a process started by torch.distributed.run still carries the elastic agent's store flag: the pool hosts its OWN store
+    # (round 6: the pool leg of `bench.py --gpus N`, started from a rank that had left its group, timed out in the rendezvous)
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
     pool = TrialWorkerPool([None, None], _runner_factory, (2,))
     assert workers.active_pool() is pool
     procs = [proc for proc, _ in pool.workers]
