@@ -278,17 +278,17 @@ def parity_leg(device, model_name):
     oracle/make_golden.py golden_resnet18_24k) the objective and sign(d total / dx) -- what hard-sign Adam consumes -- against the
     reference's history[k] and sign map, next to the reference's OWN agreement with itself when x_k moves by <= 16 ulp.
 
-    Three evaluations on this GPU, so that a deviation from the CPU reference has an owner:
-      * `control`      PyTorch-ROCm ops only -- oracle/restate.py's statements (the checker, pinned to the reference by
-                       tests/test_oracle_pinning.py), torch's own BatchNorm; no kernel of libbreach_hip.so.  Its deviation from the
-                       CPU reference is MIOpen-vs-oneDNN in the victim's convolutions at a kink-dense late iterate.
-      * `kernels_A_C`  the HIP objective and prior (kernel A behind the double backward, kernel C) on the STOCK BatchNorm modules:
-                       the same victim arithmetic as the control, so |kernels_A_C - control| is what the attack-side kernels add.
-                       Held to north_star's 1e-4 outright.
-      * the timed path kernels A, C AND kernel E (eval BatchNorm as y = x * s_c + t_c, one rounding away from torch's
-                       (x - mean) * inv_std * w + b): last-ulp differences in the activations move ReLU kinks, which is what the
-                       fixture's recorded `kink_sensitivity` measures on the reference itself (its loss moves that much when x_k
-                       moves <= 16 ulp).  Held to max(1e-4, 3 x the control's own deviation, 3 x that sensitivity)."""
+    So that a deviation from the CPU reference has an owner, on this GPU in this run:
+      * `control`      the evaluation with PyTorch-ROCm ops only -- oracle/restate.py's statements (the checker, pinned to the reference
+                       by tests/test_oracle_pinning.py), torch's own BatchNorm; no kernel of libbreach_hip.so.  Its deviation from the CPU
+                       reference is the victim's convolutions on MIOpen instead of oneDNN at a kink-dense late iterate.
+      * `kernels_A_C`  kernel A behind the double backward + kernel C on the STOCK BatchNorm modules (a victim pass of its own);
+        the timed path the same with kernel E (eval BatchNorm as y = x * s_c + t_c).
+      * `kernels_on_the_same_inputs`  kernel A (value and backward) and kernel C against the restatement's torch ops on the SAME
+                       reconstructed gradient list and the same x_k: the comparison no vendor-library choice can enter.  Held to
+                       north_star's 1e-4 outright (measured: 1e-7).
+    The full evaluations are each held to max(1e-4, 3 x the fixture's 16-ulp sensitivity): round 6 found that two victim passes of the
+    same expression in one process agree to 2e-7 or differ by 3-7e-4 depending on what ran before (MIOpen) -- control and HIP path alike."""
     import copy
 
     import numpy as np
@@ -333,38 +333,66 @@ def parity_leg(device, model_name):
     cfg, labels, total, g = hip_evaluation([])                                   # the timed path
     _, _, total_ac, g_ac = hip_evaluation(["impl.fast_eval_bn=False"])           # kernels A and C on the stock BatchNorm modules
     control_model = copy.deepcopy(case.model).to(device).eval()
+    data = [t.to(device) for t in case.shared_data[0]["gradients"]]
     xc = torch.as_tensor(gold["forced_x"][i]).to(device).clone().requires_grad_(True)
     task = case.loss_fn(control_model(xc), labels)
     rec_grads = torch.autograd.grad(task, tuple(control_model.parameters()), create_graph=True)
-    control_total = restate.gradient_objective("cosine-similarity", rec_grads, [t.to(device) for t in case.shared_data[0]["gradients"]], cfg.objective)
+    control_total = restate.gradient_objective("cosine-similarity", rec_grads, data, cfg.objective)
     control_total = control_total + restate.total_variation(xc, **cfg.regularization["total_variation"])
     (gc,) = torch.autograd.grad(control_total, [xc])
     control = against_reference(control_total, gc)
     control["what"] = ("the same evaluation on this GPU with PyTorch-ROCm ops only (oracle/restate.py statements, torch BatchNorm): the "
                        "victim's convolutions as in the HIP path, no kernel of libbreach_hip.so")
     kernels_ac = against_reference(total_ac, g_ac)
-    kernels_ac.update(what="kernel A (behind the double backward) + kernel C on the stock BatchNorm modules (impl.fast_eval_bn=False): the control's "
-                           "victim arithmetic, so the difference to the control is the attack-side kernels' own",
-                      loss_vs_control_rel=abs(float(total_ac) - float(control_total)) / abs(float(control_total)),
-                      sign_agreement_vs_control=float((torch.sign(g_ac.cpu()) == torch.sign(gc.detach().cpu())).double().mean()),
-                      tolerance_vs_control=1e-4)
+    kernels_ac.update(what="kernel A (behind the double backward) + kernel C on the stock BatchNorm modules (impl.fast_eval_bn=False), a victim pass "
+                           "of its own", loss_vs_control_rel=abs(float(total_ac) - float(control_total.detach())) / abs(float(control_total.detach())),
+                      sign_agreement_vs_control=float((torch.sign(g_ac.cpu()) == torch.sign(gc.detach().cpu())).double().mean()))
+    # Kernels A and C against torch ops ON THE SAME INPUTS -- the control's own reconstructed gradient list (one victim pass, shared) and
+    # x_k: the one comparison on this GPU that vendor-library algorithm choices cannot enter.  Value, and the gradient kernel A's
+    # backward hands to the double backward (max deviation over all 11.7 M elements, relative to the largest element).
+    from breaching_amd.gm import objective_lookup as hip_objectives
+    from breaching_amd.priors import HipTotalVariation
+
+    def value_and_gradients(objective_fn, inputs):
+        leaves = [t.detach().clone().requires_grad_(True) for t in inputs]
+        value = objective_fn(leaves)
+        return value.detach().reshape(-1)[0], [t.detach() for t in torch.autograd.grad(value.sum(), leaves)]
+
+    hip_objective = hip_objectives[cfg.objective.type](**cfg.objective)
+    hip_objective.initialize(case.loss_fn, cfg.impl, None)
+    v_t, g_t = value_and_gradients(lambda rec: restate.gradient_objective("cosine-similarity", rec, data, cfg.objective), rec_grads)
+    v_h, g_h = value_and_gradients(lambda rec: hip_objective.gradient_based_loss(rec, data), rec_grads)
+    peak = max(float(t.abs().max()) for t in g_t)
+    tv_t, tvg_t = value_and_gradients(lambda xs: restate.total_variation(xs[0], **cfg.regularization["total_variation"]), [xc])
+    tv_h, tvg_h = value_and_gradients(lambda xs: HipTotalVariation(dict(device=device, dtype=torch.float), **cfg.regularization["total_variation"])(xs[0]), [xc])
+    same_inputs = dict(
+        what="kernel A (value + backward) and kernel C (value + gradient) against oracle/restate.py's torch statements on the SAME inputs: the "
+             "control's reconstructed gradient list (62 tensors, 11.7 M elements) and x_k -- no victim pass in between, nothing vendor-chosen",
+        gm_value_rel=abs(float(v_h) - float(v_t)) / abs(float(v_t)),
+        gm_gradient_max_dev_over_peak=max(float((a - b).abs().max()) for a, b in zip(g_h, g_t)) / peak,
+        tv_value_rel=abs(float(tv_h) - float(tv_t)) / abs(float(tv_t)),
+        tv_gradient_max_dev_over_peak=float((tvg_h[0] - tvg_t[0]).abs().max()) / float(tvg_t[0].abs().max()), tolerance=1e-4)
+    same_inputs["ok"] = bool(max(same_inputs["gm_value_rel"], same_inputs["gm_gradient_max_dev_over_peak"], same_inputs["tv_value_rel"],
+                                 same_inputs["tv_gradient_max_dev_over_peak"]) <= same_inputs["tolerance"])
     sensitivity = float(gold["forced_sensitivity"][i])
     ref_psnr = np.concatenate([[gold["psnr"]], gold["twin_psnr"]])
     timed = against_reference(total, g)
+    tolerance = max(1e-4, 3.0 * sensitivity)
     out = dict(fixture="tests/golden/attack_resnet18_24k.npz (unmodified reference on CPU, 24 000 iterations)", iterate=k,
-               loss_reference=want, loss_hip=timed["loss"], loss_rel_err=timed["loss_rel_err"],
-               loss_tolerance=max(1e-4, 3.0 * control["loss_rel_err"], 3.0 * sensitivity),
-               loss_tolerance_is="max(1e-4, 3 x control.loss_rel_err, 3 x kink_sensitivity_recorded): the timed path includes kernel E's BatchNorm, "
-                                 "one rounding away from torch's -- an ulp-level perturbation of the activations, which is what the sensitivity measures",
-               control=control, kernels_A_C=kernels_ac,
-               loss_hip_vs_control_rel=abs(timed["loss"] - float(control_total)) / abs(float(control_total)),
+               loss_reference=want, loss_hip=timed["loss"], loss_rel_err=timed["loss_rel_err"], loss_tolerance=tolerance,
+               loss_tolerance_is="max(1e-4, 3 x kink_sensitivity_recorded) for EVERY full evaluation on this GPU, the control included: a victim pass "
+                                 "goes through MIOpen, whose algorithm choice is not a function of the problem alone -- two evaluations of the same "
+                                 "expression in one process agree to 2e-7 or differ by 3-7e-4 here depending on what ran before (round 6: seen on the "
+                                 "control and on the HIP path alike) -- and the fixture's sensitivity is what an ulp-level perturbation does to the "
+                                 "reference itself at this iterate.  What the attack-side kernels add is `kernels_on_the_same_inputs`, held to 1e-4 outright",
+               control=control, kernels_A_C=kernels_ac, kernels_on_the_same_inputs=same_inputs,
+               loss_hip_vs_control_rel=abs(timed["loss"] - float(control_total.detach())) / abs(float(control_total.detach())),
                kink_sensitivity_recorded=sensitivity,
                sign_agreement=timed["sign_agreement"], reference_twin_agreement=float(gold["forced_twin_sign_agreement"][i]),
                weighted_sign_agreement=timed["weighted_sign_agreement"],
                reference_twin_weighted_agreement=float(gold["forced_twin_weighted_sign_agreement"][i]),
                psnr_db_reference_runs=dict(mean=round(float(ref_psnr.mean()), 4), n=int(len(ref_psnr))))
-    out["ok"] = bool(out["loss_rel_err"] <= out["loss_tolerance"] and kernels_ac["loss_vs_control_rel"] <= kernels_ac["tolerance_vs_control"]
-                     and kernels_ac["loss_rel_err"] <= max(1e-4, 3.0 * control["loss_rel_err"])
+    out["ok"] = bool(same_inputs["ok"] and max(out["loss_rel_err"], control["loss_rel_err"], kernels_ac["loss_rel_err"]) <= tolerance
                      and 1 - out["sign_agreement"] <= 3 * (1 - out["reference_twin_agreement"]) + 1e-3)
     hip_runs = os.path.join(ROOT, "profiles", "r5_config1_24k_8starts.json")  # free-running HIP runs of the full horizon (committed)
     if os.path.exists(hip_runs):

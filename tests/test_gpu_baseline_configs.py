@@ -481,8 +481,13 @@ def test_tag_bert_base_whole_run_at_the_shipped_schedule(golden_dir):
     assert agree >= twin_agree - 1.0 / 32  # as well as the reference agrees with itself (1.0), give or take one of the 32 positions
     emb, emb_ref, emb_twin = rec["raw_embeddings"].cpu().numpy(), gold["raw_embeddings"], gold["twin_raw_embeddings"]
     close, twin_close = np.isclose(emb, emb_ref, rtol=2e-3, atol=2e-4).mean(), np.isclose(emb_twin, emb_ref, rtol=2e-3, atol=2e-4).mean()
-    print(f"  raw embeddings within 2e-3 of the reference's: hip {close:.4f}, reference twin {twin_close:.4f}")
-    assert close >= min(0.995, 0.5 * twin_close)  # noise-dominated at the end of a chaotic run (the reference's own twin: 0.14): an order-of-magnitude check
+    rms = lambda a: float(np.sqrt(np.mean((a.astype(np.float64) - emb_ref.astype(np.float64)) ** 2)))  # noqa: E731
+    d_hip, d_twin = rms(emb), rms(emb_twin)
+    print(f"  raw embeddings within 2e-3 of the reference's: hip {close:.4f}, reference twin {twin_close:.4f} (diagnostic); rms distance to the "
+          f"reference's embeddings: hip {d_hip:.3e}, reference twin {d_twin:.3e}")
+    # a comparison that can fail (advisor, round 5): the HIP run ends as close to the reference's embeddings as the reference's own
+    # 16-ulp twin does, within a factor of two -- the yardstick of the see-through test below
+    assert d_hip <= 2.0 * d_twin
 
 
 def test_resnet50_batch8_seethrough_300_iterations_on_the_shipped_schedule(golden_dir):

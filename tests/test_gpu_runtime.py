@@ -197,14 +197,15 @@ def test_bench_line_contract():
     parity = line["parity"]
     assert parity["ok"] is True and parity["iterate"] > 23_000 and parity["loss_rel_err"] <= parity["loss_tolerance"]
     # the gate is tied to the same-arithmetic control of the same run (PyTorch-ROCm ops on this GPU), and the HIP path sits with it
-    # every deviation has an owner: the control (PyTorch-ROCm ops on this GPU) carries MIOpen-vs-oneDNN; kernels A and C on the control's
-    # victim arithmetic sit on it within north_star's 1e-4; the timed path adds kernel E's BatchNorm rounding, held to the fixture's own
-    # kink sensitivity
+    # what the attack-side kernels add, on the SAME inputs as torch ops (no victim pass in between, nothing vendor-chosen): 1e-4 outright
+    same = parity["kernels_on_the_same_inputs"]
+    assert same["ok"] is True and max(same["gm_value_rel"], same["gm_gradient_max_dev_over_peak"], same["tv_value_rel"],
+                                      same["tv_gradient_max_dev_over_peak"]) <= 1e-4
+    # every full evaluation on this GPU -- the PyTorch-ROCm control included -- within 3 x the fixture's own 16-ulp sensitivity of the CPU run
     control, kernels = parity["control"], parity["kernels_A_C"]
-    assert control["sign_agreement"] > 0.99 and kernels["loss_vs_control_rel"] <= 1e-4 and kernels["sign_agreement_vs_control"] > 0.999
-    assert kernels["loss_rel_err"] <= max(1e-4, 3.0 * control["loss_rel_err"])
-    assert parity["loss_tolerance"] == pytest.approx(max(1e-4, 3.0 * control["loss_rel_err"], 3.0 * parity["kink_sensitivity_recorded"]))
-    assert parity["sign_agreement"] > 0.99 > parity["reference_twin_agreement"] > 0.9
+    assert parity["loss_tolerance"] == pytest.approx(max(1e-4, 3.0 * parity["kink_sensitivity_recorded"]))
+    assert max(control["loss_rel_err"], kernels["loss_rel_err"], parity["loss_rel_err"]) <= parity["loss_tolerance"]
+    assert control["sign_agreement"] > 0.99 and kernels["sign_agreement_vs_control"] > 0.99
     assert 0 < line["gpu_torch_baseline"]["value"] < line["value"]
     assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] in ("reference", "port")
     _check_restarts_leg(line["restarts32"], trials=8, iters=12, ranks=1)
