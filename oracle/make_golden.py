@@ -1047,14 +1047,17 @@ def golden_tag_bert_base_1000():
     assemble_tag_bert_base_1000()
 
 
-# ---- BASELINE configs[2] on its real schedule: warm-up 50 + cosine decay, Langevin noise, 300 iterations --------------------
-SEE_LONG_ITERS = 300
+# ---- BASELINE configs[2] on its real schedule: warm-up 50 + cosine decay, Langevin noise, 1 000 iterations (round 5: 300) -----
+# Three runs of ~1.5 h each (5.5 s per iteration on two threads, the three side by side):
+#   for i in 0 1 2; do python oracle/make_golden.py --seethrough-worker $i oracle/_long/see$i.npz --threads 2 & done; wait
+#   python oracle/make_golden.py --only assemble_seethrough_long
+SEE_LONG_ITERS = 1000
 SEE_LONG_RUNS = {0: dict(seed=11, ulps=0), 1: dict(seed=11, ulps=16), 2: dict(seed=12, ulps=0)}  # nominal, same-noise twin, other noise
 
 
 def _seethrough_b8_long_worker(idx, out_path, threads=1, iters=SEE_LONG_ITERS):
     """One run of the unmodified reference on ResNet-50, 8 images, seethroughgradients.yaml as shipped except for the horizon
-    (max_iterations 300 instead of 20 000: the cosine period follows it, warm-up stays 50, seethroughgradients.yaml:20-23):
+    (max_iterations 1 000 instead of 20 000: the cosine period follows it, warm-up stays 50, seethroughgradients.yaml:20-23):
     euclidean 1e-4 + TV + L2 norm + DeepInversion 0.1, Langevin noise 0.01 from torch's seeded CPU generator
     (optimization_based_attack.py:167-170), labels recovered with `yin`, user BN buffers.  idx 0 nominal; idx 1 the same noise
     stream from a start <= 16 ulp away (the reference's own reproducibility envelope); idx 2 another noise stream (what "not the

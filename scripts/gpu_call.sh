@@ -44,12 +44,12 @@ bench_n1()     { timeout 600 $B > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench
 bench_4()      { timeout 600 $B --trials-per-gpu 4 --cpu-baseline-iters 0 --no-hbm-resident > $OUT/${TAG}_bench_n1_4trials_in_flight.json 2> /dev/null; cut -c1-200 $OUT/${TAG}_bench_n1_4trials_in_flight.json; }
 bench_8ranks() { timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 20 --warmup 5 --restarts32-iters ${POOL_ITERS:-100} > $OUT/${TAG}_bench_8ranks_one_gpu.json 2> $OUT/${TAG}_bench_8ranks_one_gpu.err; tail -1 $OUT/${TAG}_bench_8ranks_one_gpu.json | cut -c1-900; tail -3 $OUT/${TAG}_bench_8ranks_one_gpu.err | cut -c1-300; }
 trace_bench()  {
-  prof 400 bench "" $B --steps 100 --warmup 20 --cpu-baseline-iters 0 --gpu-torch-baseline-iters 0 --no-parity --no-span-timing --no-hbm-resident --no-dry-collective
+  prof 400 bench "" $B --steps 100 --warmup 20 --cpu-baseline-iters 0 --gpu-torch-baseline-iters 0 --no-parity --no-span-timing --no-hbm-resident --no-dry-collective --restarts32-iters 0
   trace=$(ls -S $(find /tmp/prof_${TAG}_bench -name "*kernel_trace.csv") | head -1)
-  [ -n "$trace" ] && python scripts/gap_census.py $trace $OUT/${TAG}_1trial_gap_census --iters 60 --skip-tail 45 --label "1 trial, round 5 HEAD" | head -20
+  [ -n "$trace" ] && python scripts/gap_census.py $trace $OUT/${TAG}_1trial_gap_census --iters 60 --skip-tail 45 --label "1 trial, round 6 HEAD" | head -20
 }
 trace_bench_eager() {  # the launch mode bench.py's event-timed roofline iterations run in (a replayed graph cannot carry event pairs)
-  prof 400 bench_eager "" $B --steps 100 --warmup 20 --no-graph --cpu-baseline-iters 0 --gpu-torch-baseline-iters 0 --no-parity --no-span-timing --no-hbm-resident --no-dry-collective
+  prof 400 bench_eager "" $B --steps 100 --warmup 20 --no-graph --cpu-baseline-iters 0 --gpu-torch-baseline-iters 0 --no-parity --no-span-timing --no-hbm-resident --no-dry-collective --restarts32-iters 0
 }
 trace5()   { prof 400 config5_bert_tag "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 5; }
 trace3()   { prof 400 config3_resnet50_seethrough "" python $GRAFT_REPO_ROOT/scripts/config_runs.py --only 3; }
@@ -78,6 +78,7 @@ stepprior_trace() {
 mt_trace() { prof 200 mt_kernel_probe "" python $GRAFT_REPO_ROOT/scripts/mt_kernel_probe.py --launches 20; }
 
 # ---- round 6 ----
+suite_all() { timeout 3000 python -m pytest tests -m gpu -q -s > $OUT/${TAG}_gpu_tests.log 2>&1; tail -1 $OUT/${TAG}_gpu_tests.log | cut -c1-200; grep "^FAILED" $OUT/${TAG}_gpu_tests.log | cut -c1-200; }
 affine()   {  # kernel E layer by layer at B = 8: rocprofv3 kernel trace of scripts/affine_layer_probe.py joined with its manifest
   rm -rf /tmp/prof_${TAG}_affine
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_${TAG}_affine -- python $GRAFT_REPO_ROOT/scripts/affine_layer_probe.py --manifest $OUT/${TAG}_affine_layer_manifest.json > $OUT/${TAG}_affine_stdout.log 2> $OUT/${TAG}_affine_stderr.log)

@@ -1,4 +1,11 @@
-"""scratch: which trials of the 4-rank pool run deviate from the single-rank run?"""
+"""Which trials of a 4-rank worker-pool run (32 restarts, ConvNet, smooth soft-sign configuration: the scenario of
+tests/test_gpu_baseline_configs.py::test_configs3_shape_32_restarts_over_four_ranks_two_groups_of_four_each) deviate from the
+single-rank run, from which iteration on and by how much?  Round 6: that test failed once on a fresh box (trial 1 = the first trial
+of worker rank 1, from iteration 1, 16 %), and the round-5 tree showed the same signature once in 8 runs (trial 3, 7e-5); 64 runs at
+HEAD were clean (profiles/r6_pool_flake_probe.log).  Extra arguments are config overrides.
+
+    for i in $(seq 16); do python scripts/pool_flake_probe.py | grep deviating; done
+"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

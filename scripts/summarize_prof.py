@@ -10,7 +10,7 @@ OURS = ("gm_fwd_kernel", "gm_bwd_kernel", "gm_finalize_kernel", "tv_norm_kernel"
         "bn_sums_kernel", "bn_finalize_kernel", "bn_bwd_kernel", "bn_bwd_acc_kernel", "mt_kernel", "orthogonality_kernel", "psnr_mse_kernel",
         "grad_sumsq", "gm_pack_kernel", "state_reset", "bn_eval_fwd_kernel", "bn_eval_bwd_kernel", "bn_eval_bwd_bwd_kernel",
         "bn_eval_combine_kernel", "ln_fwd_kernel", "ln_bwd_", "grad_norm_finalize_kernel", "psnr_finalize_kernel", "tv_norm_vec4_kernel",
-        "candidate_step_vec4_kernel")
+        "candidate_step_vec4_kernel", "candidate_step_list_kernel")
 src, out = sys.argv[1], sys.argv[2]
 counter = sys.argv[3] if len(sys.argv) > 3 else None
 files = {f: os.path.join(src, f) for f in os.listdir(src)}

@@ -490,18 +490,18 @@ def test_tag_bert_base_whole_run_at_the_shipped_schedule(golden_dir):
     assert d_hip <= 2.0 * d_twin
 
 
-def test_resnet50_batch8_seethrough_300_iterations_on_the_shipped_schedule(golden_dir):
+def test_resnet50_batch8_seethrough_1000_iterations_on_the_shipped_schedule(golden_dir):
     """BASELINE configs[2] on its real schedule -- warm-up 50, cosine decay, Langevin noise 0.01, yin labels, DeepInversion
-    (seethroughgradients.yaml:20-36) -- for 300 iterations (the horizon is the one thing shortened: the stated 20 000 would be a
-    week of CPU for the reference) against three runs of the unmodified reference (oracle/make_golden.py golden_seethrough_b8_long):
-    nominal, the same noise stream from a start <= 16 ulp away, and another noise stream.  Both sides add identical noise
-    (`impl.langevin_noise=host` re-creates the reference's CPU generator stream).  Plain Adam, no sign, but pixels whose gradient is
-    below the noise follow rounding through Adam's normalisation: the reference's own twin leaves the 1e-4 band at iteration 19 and
-    peaks at 1.4e-3 (a run with ANOTHER noise stream sits at 1.3e-3 in the median -- the loss history barely tells noise streams
-    apart, the reconstruction does: rms pixel distance 0.31 for the twin, 1.12 for the other stream).  Held to: strict 1e-4 for the
-    first three iterations, then 3x the twin's running envelope with a floor of 3e-4 (the run-to-run wobble of our own GPU runs at
-    batch 8); opt_value likewise; PSNR within 0.1 dB; and the reconstruction within 2x the twin's distance of the reference's and well
-    inside the other-noise distance.  Loop: optimization_based_attack.py:110-143,167-170."""
+    (seethroughgradients.yaml:20-36) -- for 1 000 iterations (round 5: 300; the horizon is the one thing shortened: the stated 20 000
+    would be a week of CPU for the reference, 1 000 are 1.5 h per run) against three runs of the unmodified reference
+    (oracle/make_golden.py golden_seethrough_b8_long): nominal, the same noise stream from a start <= 16 ulp away, and another noise
+    stream.  Both sides add identical noise (`impl.langevin_noise=host` re-creates the reference's CPU generator stream).  Plain Adam,
+    no sign, but pixels whose gradient is below the noise follow rounding through Adam's normalisation: the reference's own twin
+    leaves the 1e-4 band at iteration 24 and peaks at 8.3e-4 (a run with ANOTHER noise stream sits at 3.6e-4 in the median -- the loss
+    history barely tells noise streams apart, the reconstruction does).  Held to: strict 1e-4 for the first three iterations, then 3x
+    the twin's running envelope with a floor of 3e-4 (the run-to-run wobble of our own GPU runs at batch 8); opt_value likewise; PSNR
+    within 0.1 dB; and the reconstruction within 2x the twin's distance of the reference's and well inside the other-noise distance.
+    Loop: optimization_based_attack.py:110-143,167-170."""
     from breaching_amd import get_attack_config, prepare_attack
     from breaching_amd.cases import build_case, initial_candidate, parameter_checksum, psnr
 
@@ -526,14 +526,18 @@ def test_resnet50_batch8_seethrough_300_iterations_on_the_shipped_schedule(golde
     rel = np.abs(hist - ref) / np.abs(ref)
     envelope = _running_envelope(gold["twin_history"], ref)
     other = np.abs(gold["other_noise_history"].astype(np.float64) - ref) / np.abs(ref)
-    # two of OUR OWN runs of this configuration differ by ~3e-4 (MIOpen's batch > 1 backward-weight kernels use atomics, HISTORY.md
-    # section 5): that is the floor once the first iterations are past; above it 3x the reference twin's running envelope
+    # floor 3e-4 once the first iterations are past: BELOW the median deviation of the reference's own run with another noise stream
+    # (3.6e-4 in this fixture) -- the loss history cannot tell two reference runs apart any finer than that -- and what two of our own
+    # batch-8 runs differ by (MIOpen's backward-weight atomics); above it 3x the reference twin's running envelope.  The gate WITHOUT
+    # the floor is printed below (round 6, 1 000 iterations: no iteration outside it, worst 0.79x)
     tol = np.maximum(np.where(np.arange(its) < 3, LOSS_RTOL, 3e-4), 3.0 * envelope)
     first_open = int(np.argmax(envelope > LOSS_RTOL)) if (envelope > LOSS_RTOL).any() else its
     print(f"  loss {ref[0]:.3f} -> {ref[-1]:.3f} (hip {hist[-1]:.3f}); twin within 1e-4 for the first {first_open} iterations, its envelope at "
           f"the end {envelope[-1]:.2e}; hip max rel dev {rel.max():.2e} (at the end {rel[-1]:.2e}); other noise stream: median {np.median(other):.2e}")
     twin_dev = np.abs(gold["twin_history"].astype(np.float64) - ref) / np.abs(ref)
-    marks = [0, 2, 5, 10, 15, 20, 25, 30, 40, 50, 60, 80, 100, 150, 200, 250, its - 1]
+    marks = [m for m in (0, 2, 5, 10, 15, 20, 25, 30, 40, 50, 60, 80, 100, 150, 200, 250, 400, 600, 800) if m < its - 1] + [its - 1]
+    strict_tol = np.maximum(LOSS_RTOL, 3.0 * envelope)  # diagnostic: the same gate without the 3e-4 floor
+    print(f"  without the floor: {int((rel > strict_tol).sum())} iterations outside max(1e-4, 3 x envelope), worst {float((rel / strict_tol).max()):.2f}x at {int((rel / strict_tol).argmax())}")
     print("  iteration      " + " ".join(f"{m:>8d}" for m in marks))
     print("  hip rel dev    " + " ".join(f"{rel[m]:8.1e}" for m in marks))
     print("  twin rel dev   " + " ".join(f"{twin_dev[m]:8.1e}" for m in marks))

@@ -623,11 +623,12 @@ def test_pending_batchnorm_absorbs_residual_and_relu_without_changing_the_model(
 
 
 def test_design_tables_are_generated_from_the_committed_profiles():
-    """DESIGN.md section 6's round-5 tables are the output of scripts/design_tables.py over the files under profiles/: a number
-    in the text cannot drift from the committed evidence (round 3 had a quoted 40.2 / 47.6 us that the summary file no longer
-    showed).  Regenerate with `python scripts/design_tables.py --write`."""
+    """DESIGN.md section 6's round-6 block and profiles/TABLES.md (the round-5 tables in full) are the output of
+    scripts/design_tables.py over the files under profiles/: a number in the text cannot drift from the committed evidence (round 3
+    had a quoted 40.2 / 47.6 us that the summary file no longer showed).  Regenerate with `python scripts/design_tables.py --write`."""
     import importlib.util
     import os
+    import re
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("design_tables", os.path.join(root, "scripts", "design_tables.py"))
@@ -637,13 +638,18 @@ def test_design_tables_are_generated_from_the_committed_profiles():
     assert module.BEGIN in text and module.END in text
     block = text[text.index(module.BEGIN): text.index(module.END) + len(module.END)]
     assert block == module.build(), "DESIGN.md is stale: run `python scripts/design_tables.py --write`"
-    # the files the block quotes exist
-    import re
-
-    quoted = set(re.findall(r"`(r5_[A-Za-z0-9_.]+\.(?:json|jsonl|txt|csv))`", block))
-    assert len(quoted) >= 12, quoted
-    for name in quoted | {"r5_bench_driver_style.json", "r5_bench_kernel_summary.txt", "r5_read_ceiling_probe.jsonl", "r5_hip_64starts_1000its.json"}:
+    detail = open(module.DETAIL_PATH).read()
+    assert detail == module.DETAIL_HEAD + module.build_detail() + "\n", "profiles/TABLES.md is stale: run `python scripts/design_tables.py --write`"
+    # the files the two blocks quote exist, and the round-6 block covers what the round-5 review asked the line to carry
+    quoted = set(re.findall(r"`(r[56]_[A-Za-z0-9_.]+\.(?:json|jsonl|txt|csv))`", block + detail))
+    assert len([q for q in quoted if q.startswith("r6_")]) >= 8 and len([q for q in quoted if q.startswith("r5_")]) >= 12, quoted
+    for name in quoted | {"r6_bench_driver_style.json", "r6_bench_kernel_summary.txt", "r6_affine_layers.json", "r5_read_ceiling_probe.jsonl",
+                          "r5_hip_64starts_1000its.json"}:
         assert os.path.exists(os.path.join(root, "profiles", name)), name
+    for needle in ("BASELINE configs[3] through `attacker.reconstruct`", "Kernel E at BASELINE configs[2]'s batch size", "on the SAME inputs",
+                   "Trial batching, decided with a number", "Joint data + label attack"):
+        assert needle in block, needle
+    assert len(text) < 36_000  # the current-state document stays readable; history lives in HISTORY.md
 
 
 def test_bench_hbm_resident_list_is_bert_base_without_the_word_embedding():
