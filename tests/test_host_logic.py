@@ -674,10 +674,10 @@ def test_bench_hbm_resident_list_is_bert_base_without_the_word_embedding():
     n = 11_689_512
     sources = []
     fwd, bwd = bench.pmc_traffic_bytes("gm_fwd_kernel", sources), bench.pmc_traffic_bytes("gm_bwd_kernel")
-    assert sources and all(name.startswith("r5_pmc_") for name in sources)
+    assert sources and all(name.startswith("r6_pmc_") for name in sources)
     assert 1.0 <= fwd / (2 * n * 4) <= 1.01 and 1.0 <= bwd / (3 * n * 4) <= 1.01
     us, name = bench.committed_replay_duration("gm_fwd_kernel<0")
-    assert name == "r5_bench_kernel_summary.txt" and 12.0 < us < 25.0
+    assert name == "r6_bench_kernel_summary.txt" and 12.0 < us < 25.0
 
 
 def test_bench_cpu_baseline_is_the_unmodified_reference_when_a_checkout_is_importable(monkeypatch):
