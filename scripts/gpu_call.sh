@@ -88,6 +88,7 @@ affine()   {  # kernel E layer by layer at B = 8: rocprofv3 kernel trace of scri
 }
 pool8()    { timeout 900 $B --restarts32-pool 8 --restarts32-iters ${POOL_ITERS:-100} > $OUT/${TAG}_restarts32_pool8_one_gpu.json 2> $OUT/${TAG}_restarts32_pool8_one_gpu.err; tail -1 $OUT/${TAG}_restarts32_pool8_one_gpu.json | cut -c1-1500; tail -3 $OUT/${TAG}_restarts32_pool8_one_gpu.err | cut -c1-300; }
 pool2()    { timeout 900 $B --restarts32-pool 2 --restarts32-iters ${POOL_ITERS:-1000} > $OUT/${TAG}_restarts32_pool2_one_gpu.json 2> $OUT/${TAG}_restarts32_pool2_one_gpu.err; tail -1 $OUT/${TAG}_restarts32_pool2_one_gpu.json | cut -c1-1500; tail -3 $OUT/${TAG}_restarts32_pool2_one_gpu.err | cut -c1-300; }
+tailprobe() { timeout 200 python scripts/tail_probe.py > $OUT/${TAG}_tail_probe.jsonl 2> $OUT/${TAG}_tail_probe.err; cat $OUT/${TAG}_tail_probe.jsonl; tail -2 $OUT/${TAG}_tail_probe.err | cut -c1-300; }
 batched()  {  # trial batching decided with a number: vmap(grad) over K restarts in one victim pass vs 4 in flight (553 it/s)
   for k in 4 8 16; do
     timeout 300 python scripts/batched_restarts_probe.py --trials $k --steps 40 --only batched >> $OUT/${TAG}_batched_restarts_probe.jsonl 2>> $OUT/${TAG}_batched_restarts_probe.err
