@@ -443,6 +443,49 @@ def test_trials_in_flight_share_priors_with_per_trial_state():
     assert_same_attack(runs[4], runs[1], control=runs["control"])
 
 
+@pytest.mark.parametrize("family", ["invertinggradients", "legacy"])
+def test_later_trial_groups_rearm_the_captured_graphs_and_match_sequential_trials(family):
+    """Ten restarts, four in flight: groups 2 and 3 RE-ARM the first group's trials (new starting point copied into the captured
+    candidate tensors; moments, best copy, history and state record reset) instead of building and capturing new ones -- every trial's
+    history, the winner and its candidate equal the strictly sequential run (each trial a fresh object, three eager iterations, its own
+    capture).  `legacy`: DeepInversion + feature hooks + double-opponent TV, whose device buffers the captured graphs keep writing to
+    (a re-armed group must not re-initialise them).  optimization_based_attack.py:70-78: the loop being reorganised."""
+    from breaching_amd import attacker as attacker_module
+    from breaching_amd import get_attack_config
+    from breaching_amd.cases import build_case
+    from conftest import assert_same_attack
+
+    if family == "legacy":
+        over = ["optim.max_iterations=12", "optim.callback=6", "restarts.num_trials=10", "init=randn",
+                "regularization.deep_inversion.scale=0.001", "regularization.features.scale=0.1"]
+        case = build_case("convnet", "CIFAR10", 1, device="cuda:0", provide_buffers=True)
+    else:
+        over = ["objective.type=euclidean", "objective.scale=0.01", "optim.signed=soft", "optim.max_iterations=12",
+                "restarts.num_trials=10", "restarts.scoring=euclidean", "optim.callback=6"]
+        case = build_case("convnet", "CIFAR10", 1, device="cuda:0")
+    built = []
+    original = attacker_module.FusedTrial.__init__
+
+    def counting(self, *args, **kwargs):
+        built.append(1)
+        return original(self, *args, **kwargs)
+
+    runs = {}
+    attacker_module.FusedTrial.__init__ = counting
+    try:
+        for width in (1, "control", 4):
+            built.clear()
+            rec, stats, _ = _attack(case, get_attack_config(family, over + [f"impl.trials_in_flight={1 if width == 'control' else width}"]), None, seed=3)
+            assert stats["execution"]["trials"] == {t: "hipGraph replay" for t in range(10)}
+            assert len(built) == (4 if width == 4 else 10)  # four objects serve ten trials (groups of 4 + 4 + 2)
+            runs[width] = (rec["data"], stats)
+    finally:
+        attacker_module.FusedTrial.__init__ = original
+    assert len({round(runs[4][1][f"Trial_{t}_Val"][0], 6) for t in range(10)}) == 10  # ten different starting points
+    assert all(len(runs[4][1][f"Trial_{t}_Val"]) == 12 for t in range(10))
+    assert_same_attack(runs[4], runs[1], control=runs["control"])
+
+
 def test_device_langevin_noise_under_graph_replay(golden_dir):
     """see-through-gradients with the shipped Langevin noise drawn ON THE DEVICE inside the replayed iteration
     (`torch.randn_like` captured into the hipGraph; optimization_based_attack.py:167-170).
