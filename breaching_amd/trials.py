@@ -229,8 +229,28 @@ def dry_collective(device, backend="nccl", timeout_s=120.0):
         t2 = time.perf_counter()
         ok = (value == 0.25 and solution[0].device.type == device.type and float(solution[0].flatten()[0]) == 1.0
               and float(solution[1].flatten()[0]) == -1.0 and sorted(stats) == [f"Trial_{t}_Val" for t in range(3)])
-        return dict(backend=dist.get_backend(), world=dist.get_world_size(), device=str(device), ok=bool(ok), value=value,
-                    init_s=round(t1 - t0, 3), select_s=round(t2 - t1, 3))
+        # the collective of `TrialWorkerPool.ship` (job inputs by broadcast): one flat buffer per dtype on the device, packed and
+        # unpacked with the pool's own layout code -- mixed dtypes, a ragged and an empty tensor
+        from . import workers
+
+        tree = dict(gradients=[torch.arange(7, dtype=torch.float32, device=device), torch.zeros(0, device=device),
+                               torch.arange(6, dtype=torch.float32, device=device).view(2, 3)], labels=torch.tensor([3, 1], device=device))
+        skeleton, tensors = workers.split_tensors(tree)
+        specs = [(tuple(t.shape), str(t.dtype).replace("torch.", "")) for t in tensors]
+        received = [None] * len(specs)
+        for name, (total, members) in workers.shipment_layout(specs).items():
+            flat = torch.zeros(total, dtype=getattr(torch, name), device=device)
+            for index, offset, numel in members:
+                flat[offset : offset + numel].copy_(tensors[index].reshape(-1))
+            dist.broadcast(flat, src=0)
+            for index, offset, numel in members:
+                received[index] = flat[offset : offset + numel].view(specs[index][0])
+        back = workers.join_tensors(skeleton, received)
+        ship_ok = all(torch.equal(a, b) and a.device == b.device for a, b in zip(back["gradients"] + [back["labels"]], tree["gradients"] + [tree["labels"]]))
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        return dict(backend=dist.get_backend(), world=dist.get_world_size(), device=str(device), ok=bool(ok and ship_ok), value=value,
+                    ship_ok=bool(ship_ok), init_s=round(t1 - t0, 3), select_s=round(t2 - t1, 3))
     finally:
         dist.destroy_process_group()
 

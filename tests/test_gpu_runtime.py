@@ -30,6 +30,7 @@ def test_selection_collectives_run_through_rccl_on_one_rank():
     print(" ", record)
     assert record["backend"] == "nccl" and record["world"] == 1 and record["device"] == "cuda:0"
     assert record["ok"] and record["value"] == 0.25
+    assert record["ship_ok"] is True  # the broadcast `TrialWorkerPool.ship` sends job inputs with, device flats of mixed dtypes, through RCCL
 
 
 def test_capture_failure_falls_back_visibly_and_raises_when_required(monkeypatch):
