@@ -193,6 +193,37 @@ def join(args):
     print("ceiling (diag_rw, read two write one):", manifest["ceiling"])
 
 
+def join_pmc(args):
+    """HBM traffic per launch from two `rocprofv3 --pmc` passes of this probe (FETCH_SIZE, WRITE_SIZE: separate passes, counters only;
+    values in KiB; FETCH_SIZE x 2 = the gfx950 half-count of wide coalesced reads, MI355X_MICROARCH.md) against the algorithmic bytes."""
+    with open(args.manifest) as f:
+        manifest = json.load(f)
+
+    def per_dispatch(path, counter):
+        rows = []
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") == counter and "bn_eval_" in row["Kernel_Name"] and "combine" not in row["Kernel_Name"]:
+                    rows.append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+        return [v for _, v in sorted(rows)]
+
+    fetch, write = per_dispatch(args.join_pmc[0], "FETCH_SIZE"), per_dispatch(args.join_pmc[1], "WRITE_SIZE")
+    at, out = 0, []
+    for case in manifest["launches"]:
+        f_kib, w_kib = fetch[at : at + case["reps"]], write[at : at + case["reps"]]
+        at += case["reps"]
+        assert len(f_kib) == len(w_kib) == case["reps"], (case, len(f_kib), len(w_kib))
+        traffic = (2.0 * sum(f_kib) / len(f_kib) + sum(w_kib) / len(w_kib)) * 1024.0
+        out.append(dict(order=case["order"], C=case["C"], H=case["H"], W=case["W"], epilogue=case["epilogue"], layers=case["layers"],
+                        algorithmic_bytes=case["bytes"], traffic_bytes=int(traffic), ratio=round(traffic / case["bytes"], 4)))
+    assert at == len(fetch) == len(write), (at, len(fetch), len(write))
+    with open(args.out + "_pmc.json", "w") as f:
+        json.dump(dict(batch=manifest["batch"], model=manifest["model"], rows=out), f, indent=0)
+    big = [r for r in out if r["algorithmic_bytes"] >= 19e6]
+    print("PMC traffic / algorithmic bytes, launches >= 19 MB: " + ", ".join(f"{r['order']} {r['C']}x{r['H']}x{r['W']}/{r['epilogue']} {r['ratio']:.3f}" for r in big))
+    print(f"all {len(out)} cases: min {min(r['ratio'] for r in out):.3f}, max {max(r['ratio'] for r in out):.3f}")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
@@ -200,9 +231,12 @@ if __name__ == "__main__":
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--manifest", default="gpurun_out/affine_layer_manifest.json")
     ap.add_argument("--join", default=None, help="kernel_trace.csv of a rocprofv3 run of this probe")
+    ap.add_argument("--join-pmc", nargs=2, default=None, metavar=("FETCH_CSV", "WRITE_CSV"), help="counter_collection.csv of the two --pmc passes")
     ap.add_argument("--out", default="gpurun_out/affine_layers")
     a = ap.parse_args()
-    if a.join:
+    if a.join_pmc:
+        join_pmc(a)
+    elif a.join:
         join(a)
     else:
         run(a)

@@ -86,6 +86,14 @@ affine()   {  # kernel E layer by layer at B = 8: rocprofv3 kernel trace of scri
   [ -n "$trace" ] && python scripts/affine_layer_probe.py --join $trace --manifest $OUT/${TAG}_affine_layer_manifest.json --out $OUT/${TAG}_affine_layers 2>&1 | cut -c1-900
   tail -2 $OUT/${TAG}_affine_stderr.log | cut -c1-300
 }
+affine_pmc() {  # HBM traffic of kernel E per layer: FETCH_SIZE and WRITE_SIZE in separate counter-only passes over the same probe
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof_${TAG}_affine_$c
+    (cd /tmp && timeout 400 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_${TAG}_affine_$c -- python $GRAFT_REPO_ROOT/scripts/affine_layer_probe.py --reps 4 --manifest $OUT/${TAG}_affine_pmc_manifest.json > $OUT/${TAG}_affine_pmc_$c.log 2>&1)
+  done
+  f=$(find /tmp/prof_${TAG}_affine_FETCH_SIZE -name "*counter_collection.csv" | head -1); w=$(find /tmp/prof_${TAG}_affine_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] && [ -n "$w" ] && python scripts/affine_layer_probe.py --join-pmc $f $w --manifest $OUT/${TAG}_affine_pmc_manifest.json --out $OUT/${TAG}_affine_layers 2>&1 | cut -c1-900
+}
 pool8()    { timeout 900 $B --restarts32-pool 8 --restarts32-iters ${POOL_ITERS:-100} > $OUT/${TAG}_restarts32_pool8_one_gpu.json 2> $OUT/${TAG}_restarts32_pool8_one_gpu.err; tail -1 $OUT/${TAG}_restarts32_pool8_one_gpu.json | cut -c1-1500; tail -3 $OUT/${TAG}_restarts32_pool8_one_gpu.err | cut -c1-300; }
 pool2()    { timeout 900 $B --restarts32-pool 2 --restarts32-iters ${POOL_ITERS:-1000} > $OUT/${TAG}_restarts32_pool2_one_gpu.json 2> $OUT/${TAG}_restarts32_pool2_one_gpu.err; tail -1 $OUT/${TAG}_restarts32_pool2_one_gpu.json | cut -c1-1500; tail -3 $OUT/${TAG}_restarts32_pool2_one_gpu.err | cut -c1-300; }
 tailprobe() { timeout 200 python scripts/tail_probe.py > $OUT/${TAG}_tail_probe.jsonl 2> $OUT/${TAG}_tail_probe.err; cat $OUT/${TAG}_tail_probe.jsonl; tail -2 $OUT/${TAG}_tail_probe.err | cut -c1-300; }
