@@ -247,6 +247,21 @@ def test_bench_restarts_leg_through_the_worker_pool():
     assert pool["job_ship_s"] > 0 and pool["trials_wait_s"] >= 0 and pool["select_s"] > 0 and leg["warmup_pool"]["pool_start_s"] > 0
 
 
+@pytest.mark.trial_pool
+def test_bench_restarts_leg_with_eight_pool_ranks_on_one_gpu():
+    """BASELINE configs[3]'s full shape -- 32 restarts over EIGHT ranks, four in flight each -- through the product's single-process
+    entry, as rank 0 of `bench.py --gpus 8` runs it on an 8-GPU node; here the eight ranks share cuda:0 (gloo): start-up of seven
+    workers, both shipments by broadcast, 32 graph-replayed trials, one selection.  Contract only (the trajectories of this shape are
+    compared in test_configs3_shape_32_restarts_over_four_ranks_two_groups_of_four_each)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--restarts32-pool", "8", "--restarts32-iters", "8", "--restarts32-trials", "32"]
+    proc = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    leg = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+    print(" ", {k: leg[k] for k in ("wall_s", "trial_iterations_per_s", "warmup_call_s", "pool")})
+    _check_restarts_leg(leg, trials=32, iters=8, ranks=8)
+    assert leg["pool"]["world"] == 8 and leg["trials_per_rank"] == 4 and leg["trials_in_flight_per_rank"] == 4
+
+
 def test_bench_multi_rank_launch_on_one_gpu():
     """`python bench.py --gpus 2` end to end, as the driver's scaling run launches it (torch.distributed.run, one rank per "GPU"; here
     both ranks on cuda:0 over gloo, `oversubscribed`): the staged start through rank 0's file flag (bounded -- no collective holds the
