@@ -26,8 +26,12 @@ Contract (driver):  python bench.py --gpus N --steps K --warmup W
     per lane, two multiply-adds per element instead of the objective; scripts/diag/read_ceiling.hip, NOT part of the library)
     reaches on buffers of the same size in this run, right behind a writer -- for a list that streams from the 256 MiB
     Infinity Cache (ResNet-18's does) the 8 TB/s HBM peak is the wrong denominator, this is the measured one.
-  * parity: one teacher-forced evaluation of the timed configuration at the reference's own late iterate (k = 23 991 of the
-    24 000-iteration CPU run of the unmodified reference, tests/golden/attack_resnet18_24k.npz) -- loss and step direction.
+  * parity: teacher-forced evaluations of the timed configuration at the reference's own late iterate (k = 23 991 of the
+    24 000-iteration CPU run of the unmodified reference, tests/golden/attack_resnet18_24k.npz) -- loss and step direction of the timed
+    path, of a PyTorch-ROCm-only control on the same GPU, and kernels A / C against torch ops on the SAME inputs (`parity_leg`).
+  * restarts32: BASELINE configs[3] through the product entry -- `attacker.reconstruct` with restarts.num_trials = 32 on the headline
+    workload, wall time incl. rescoring and selection: at N = 1 in this process (8 groups of 4 trials in flight), at N > 1 through the
+    product's TrialWorkerPool from rank 0 in a bounded process of its own after the ranks have left (`restarts32_leg`).
   * gpu_torch_baseline: the same attack with PyTorch-ROCm ops for the attack-side arithmetic (oracle/restate.py on the GPU, no
     kernel of libbreach_hip.so), a bounded number of iterations: what the HIP path buys ON THIS CHIP.  A reported baseline.
   * cpu_baseline: the UNMODIFIED reference through oracle/ref_shim.py when a reference checkout is importable
