@@ -164,6 +164,8 @@ _PROTOTYPES = {
     "bh_state_reset": (c_int, [c_void_p, c_void_p]),
     "bh_loss_commit": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "bh_grad_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_float, c_void_p, c_void_p]),
+    "bh_trial_key": (c_int64, [c_float, c_int32]),
+    "bh_trial_key_unpack": (c_int, [c_int64, POINTER(c_float), POINTER(c_int32)]),
     "bh_step_list_norm_rows": (c_int32, [c_int32, POINTER(StepSlot)]),
     "bh_grad_norm_list": (c_int, [c_void_p, c_int32, POINTER(StepSlot), c_void_p, c_void_p, c_void_p]),
     "bh_candidate_step_list": (c_int, [c_void_p, c_void_p, c_int32, POINTER(StepSlot), c_void_p, c_void_p]),

@@ -484,6 +484,40 @@ int bh_candidate_step_list(void* state_dev, const double* sched_dev, int32_t n_s
   return bh::launch_status();
 }
 
+int64_t bh_trial_key(float score, int32_t trial) {
+  union {
+    float f;
+    uint32_t u;
+  } bits;
+  bits.f = score;
+  const int64_t t = (int64_t)(uint32_t)trial;
+  if (score != score || score == __builtin_inff()) return ((int64_t)0x7F800000 << 32) | t;
+  if (score < 0.f) {  // below every non-negative key, relative order kept
+    bits.f = -score;
+    return -(((int64_t)bits.u << 32) | (int64_t)(0xFFFFFFFFu - (uint32_t)trial));
+  }
+  return ((int64_t)bits.u << 32) | t;
+}
+
+int bh_trial_key_unpack(int64_t key, float* score_out, int32_t* trial_out) {
+  if (score_out == nullptr || trial_out == nullptr) return BH_EINVAL;
+  union {
+    float f;
+    uint32_t u;
+  } bits;
+  if (key < 0) {
+    const int64_t mag = -key;
+    bits.u = (uint32_t)(mag >> 32);
+    *score_out = -bits.f;
+    *trial_out = (int32_t)(0xFFFFFFFFu - (uint32_t)(mag & 0xFFFFFFFF));
+    return 0;
+  }
+  bits.u = (uint32_t)(key >> 32);
+  *score_out = bits.f;
+  *trial_out = (int32_t)(key & 0xFFFFFFFF);
+  return 0;
+}
+
 int bh_event_create(void** event_out) {
   if (event_out == nullptr) return BH_EINVAL;
   hipEvent_t ev = nullptr;

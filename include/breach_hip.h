@@ -465,6 +465,16 @@ int bh_grad_norm_list(const void* state_dev, int32_t n_slots, const bh_step_slot
 int bh_candidate_step_list(void* state_dev, const double* sched_dev, int32_t n_slots, const bh_step_slot* slots, const double* ws_dev,
                            void* stream);
 
+/* Trial selection across ranks (host arithmetic; the collective itself is ONE all-reduce(MIN) on this key + one broadcast of the
+ * winner, issued by the caller over RCCL -- `torch.distributed` in breaching_amd/trials.py, `ncclAllReduce(..., ncclInt64, ncclMin, ...)`
+ * for a host without Python).  key = (IEEE-754 bits of the fp32 score << 32) | trial for scores >= 0 (their bit patterns order like
+ * the floats); NaN and +inf map to the +inf pattern (the reference turns a non-finite score into +inf, :204); negative scores, which no
+ * supported scoring produces, order below every non-negative one.  Ties go to the lower trial index, like torch.min in the
+ * reference's sequential loop.  reference: optimization_based_attack.py:191-218. */
+int64_t bh_trial_key(float score, int32_t trial);
+/* Inverse for keys >= 0 and for the negative-score keys; returns 0, or BH_EINVAL for NULL outputs. */
+int bh_trial_key_unpack(int64_t key, float* score_out, int32_t* trial_out);
+
 /* Timing helpers (thin wrappers over hipEvent*, used by bench.py for the roofline leg). */
 int bh_event_create(void** event_out);
 int bh_event_destroy(void* event);

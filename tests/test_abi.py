@@ -91,6 +91,37 @@ def test_chunk_table_host_helpers(hip_lib):
     assert hip_lib.bh_candidate_step_list(None, None, 1, None, None, None) == -1 and hip_lib.bh_step_list_norm_rows(1, None) == -1
 
 
+def test_trial_key_helpers_agree_with_the_python_selection(hip_lib):
+    """`bh_trial_key` / `bh_trial_key_unpack` (the C-ABI side of the trial selection: what a host without Python packs before its
+    ncclAllReduce(MIN)) against `breaching_amd.trials.score_key` / `unpack_key` (what `TrialShard.select` all-reduces): equal keys for
+    ordinary scores, ties, zero, denormals, NaN / +inf (the reference turns a non-finite score into +inf,
+    optimization_based_attack.py:204) and negative scores; and the ordering the selection relies on."""
+    import math
+    from ctypes import byref, c_float, c_int32
+
+    import numpy as np
+
+    from breaching_amd import trials
+
+    scores = [0.0, 1e-45, 1.1754944e-38, 0.0625, 0.25, 0.25, 1.0, 3.4028235e38, float("inf"), float("nan"), -0.5, -2.0]
+    keys = []
+    for trial, score in enumerate(scores):
+        key = hip_lib.bh_trial_key(score, trial)
+        assert key == trials.score_key(np.float32(score), trial), (score, trial)
+        got_score, got_trial = c_float(), c_int32()
+        assert hip_lib.bh_trial_key_unpack(key, byref(got_score), byref(got_trial)) == 0
+        want_score, want_trial = trials.unpack_key(key)
+        assert got_trial.value == want_trial == trial
+        assert (math.isinf(got_score.value) and math.isinf(want_score)) or got_score.value == np.float32(want_score)
+        keys.append(key)
+    finite = [(np.float32(s), t) for t, s in enumerate(scores) if s == s and s != float("inf") and s >= 0]
+    assert min(keys[t] for _, t in finite) == keys[min(finite)[1]]      # MIN over keys = argmin over (score, trial)
+    assert keys[4] < keys[5]                                             # a tie goes to the lower trial index
+    assert keys[8] >> 32 == keys[9] >> 32 == 0x7F800000                  # NaN loses like +inf
+    assert max(keys[10], keys[11]) < keys[0] and keys[11] < keys[10]     # negative scores order below, among themselves by value
+    assert hip_lib.bh_trial_key_unpack(keys[0], None, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from breaching_amd import _lib
 
