@@ -736,7 +736,9 @@ def main():
     # must not hold seven ranks in a barrier until the collective timeout aborts the job -- on time-out they go ahead unseeded
     # (`staged_start.released` / `.seeded_files` per rank in the line).
     miopen_seeded, staged_released = None, None
-    staged_flag = os.path.join("/tmp", f"bench_staged_start_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'run')}")
+    # (named after the launcher's PID -- the parent every rank of one torch.distributed.run launch shares -- so that a file left behind
+    # by a crashed earlier launch on the same port cannot release this one's ranks early)
+    staged_flag = os.path.join("/tmp", f"bench_staged_start_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")
     if world > 1 and rank > 0:
         deadline = time.time() + float(os.environ.get("BENCH_STAGED_START_TIMEOUT", "300"))
         while not os.path.exists(staged_flag) and time.time() < deadline:
